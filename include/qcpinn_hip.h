@@ -1,0 +1,138 @@
+/* libqcpinn_hip.so — C ABI of the MI355X (gfx950) QCPINN hot path.
+ *
+ * The reference (masapasa/qcpinn-convection-diffusion-qiskit) has no FFI: its hot path is Python
+ * calling PennyLane + torch autograd.  These entry points are what a binding for that path binds
+ * instead; each one names the reference code whose arithmetic it replaces.  Plain pointers and
+ * sizes only — no torch types.  Every pointer marked "dev" is a device (HBM) pointer owned by the
+ * caller; the library never allocates or frees caller memory, never synchronises the stream, and
+ * only enqueues work on `stream` (a hipStream_t passed as void*; NULL = default stream).
+ * Every function returns 0 on success or a negative QC_ERR_* code; nothing throws.
+ *
+ * Layouts (all fp32):
+ *   [f][B]      "batch-minor": feature f of point p at f*B + p (coalesced over the batch).
+ *   jets        6 derivative channels {value, d/dt, d/dx, d/dy, d2/dx2, d2/dy2} x n wires: [6][n][B].
+ *   flat params W1[H][3] b1[H] W2[n][H] b2[n] W3[H][n] b3[H] W4[H] b4 theta[n_theta]
+ *               (= torch's model.parameters() order of the reference DVPDESolver).
+ *   partial rows [rows][stride] gradients, one row per 64-point tile, columns in flat-param order
+ *               followed by 3 loss columns (residual, BC, IC); reduced in fixed order (no atomics).
+ */
+#ifndef QCPINN_HIP_H
+#define QCPINN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QC_ABI_VERSION 1
+
+typedef struct qc_program qc_program; /* device-resident gate program (opaque) */
+
+int qc_version(void);
+const char* qc_error_string(int code);
+int qc_last_hip_error(void); /* hipError_t of the last failing runtime call, 0 if none */
+
+/* ---- gate program: the lowered ansatz of DVQuantumLayer._quantum_circuit
+ * (reference nn/DVQuantumLayer.py:176-214 and the builders :246-371).
+ * gate_rows: host int32 [n_gates][4] = (opcode, wire_a, wire_b, slot); opcodes
+ * RX=0 RY=1 RZ=2 H=3 CNOT=4 CRX=5 CRZ=6 U4=7 (fixed two-wire unitary, slot 0 on wires [0,1],
+ * slot 1 on wires [2,3]).  The embedding RX(x_i) is implicit. */
+int qc_program_create(const int32_t* gate_rows, int n_gates, int n_qubits, int n_params, qc_program** out);
+int qc_program_destroy(qc_program* prog);
+size_t qc_trig_bytes(const qc_program* prog); /* size of the per-gate cos/sin workspace */
+
+/* cos/sin(theta/2) per gate; call after theta changes (the fused step does it itself). */
+int qc_prepare_gates(const qc_program* prog, const float* theta_dev, void* trig_dev, void* stream);
+
+/* ---- DVQuantumLayer.forward, simulator batch branch (nn/DVQuantumLayer.py:151-154):
+ * angles [n][B] -> <Z_w> [n][B].  umat_dev: [2 slots][fwd, adjoint][4x4 complex] floats or NULL. */
+int qc_forward_expval(const qc_program* prog, const void* trig_dev, const float* umat_dev,
+                      const float* angles_dev, float* expval_dev, int64_t B, void* stream);
+/* its vector-Jacobian product (what loss.backward() asks of PennyLane's backprop):
+ * cot [n][B] -> d_angles [n][B] and d_theta as partial rows at columns [0, n_params) of `part`. */
+int qc_backward_expval(const qc_program* prog, const void* trig_dev, const float* umat_dev,
+                       const float* angles_dev, const float* cot_dev, float* d_angles_dev,
+                       float* part_dev, int64_t part_stride, int64_t row0, int64_t B, void* stream);
+
+/* ---- the same layer carrying the derivative channels that nn/pde.py:59-70 obtains with five
+ * torch.autograd.grad(create_graph=True) calls through the simulator. */
+int qc_forward_jets(const qc_program* prog, const void* trig_dev, const float* umat_dev,
+                    const float* ajets_dev, float* qjets_dev, int64_t B, void* stream);
+int qc_backward_jets(const qc_program* prog, const void* trig_dev, const float* umat_dev,
+                     const float* ajets_dev, const float* qbar_dev, float* abar_dev, float* part_dev,
+                     int64_t part_stride, int64_t row0, int64_t B, void* stream);
+
+/* ---- classical pre/post networks of DVPDESolver.forward (nn/DVPDESolver.py:37-51,81-110) with
+ * the same channels.  nch = 6 (residual points) or 1 (boundary/initial points). */
+int qc_pre_forward(const float* X_dev /*[B][3]*/, const float* params_dev, int H, int n, int n_theta,
+                   float* ajets_dev, int64_t B, int nch, void* stream);
+int qc_pre_backward(const float* X_dev, const float* params_dev, int H, int n, int n_theta,
+                    const float* abar_dev, float* part_dev, int64_t part_stride, int64_t row0, int64_t B,
+                    int nch, void* stream);
+
+typedef struct qc_pde {
+  float D, vx, vy;        /* nn/pde.py:53-55 defaults 0.01, 1, 1 */
+  float w_res;            /* d loss / d residual scale: 2*weight/N (weight 2, trainer/diffusion_train.py:47) */
+  float inv_n_res;        /* 1/N for the logged MSE */
+  float w_val_a, w_val_b; /* same for the value segments: a = IC (weight 2), b = BC (weight 4) */
+  float inv_n_a, inv_n_b;
+  int64_t n_seg_a;        /* leading value points that are IC points */
+} qc_pde;
+
+/* mode 0: qjets -> u [B], residual [B] (nn/pde.py:71);
+ * mode 1: cotangents (ubar, rbar) [B] -> qbar jets + weight-gradient partial rows;
+ * mode 2: forward + analytic targets (data/diffusion_dataset.py:20-38) + squared error + reverse. */
+int qc_post(int mode, const float* X_dev, const float* params_dev, int H, int n, int n_theta,
+            const qc_pde* pde, const float* qjets_dev, float* out_u_dev, float* out_res_dev,
+            const float* in_ubar_dev, const float* in_rbar_dev, float* qbar_dev, float* part_dev,
+            int64_t part_stride, int64_t row0, int64_t B, int nch, void* stream);
+
+/* ---- optimiser block of the step (trainer/diffusion_train.py:81-90) */
+int qc_reduce_rows(const float* part_dev, int64_t rows, int64_t stride, int ncols, float* out_dev, void* stream);
+
+typedef struct qc_opt_hyper {
+  double beta1, beta2;
+  float eps, max_norm;
+  float sched_factor, sched_threshold, sched_min_lr, sched_eps;
+  int sched_patience;
+  float w_res, w_bc, w_ic;
+} qc_opt_hyper;
+
+/* opt_state_dev: 64-byte record {lr, best, num_bad, step, last_loss, last_norm, loss_parts[3]}.
+ * flat_dev = [grad[NP] | L_r, L_bc, L_ic].  Clips, applies Adam, steps the plateau scheduler,
+ * appends the loss to hist_dev[step] and refreshes the trig table from the new theta. */
+int qc_adam_step(float* flat_dev, int NP, float* params_dev, float* m_dev, float* v_dev, void* opt_state_dev,
+                 const qc_opt_hyper* hp, float* hist_dev, int hist_cap, const qc_program* prog, int theta_off,
+                 void* trig_dev, void* stream);
+
+/* ---- one whole training step (trainer/diffusion_train.py:30-49,81-90) on resident batches:
+ * residual batch through the 6-channel pipeline, IC+BC batch through the value pipeline,
+ * row reduction, then (phase 2) clip + Adam + scheduler.  With `phases` = 1 it stops after the
+ * reduction so the caller can all-reduce `flat_dev` across ranks, then calls again with 2. */
+typedef struct qc_step_desc {
+  const qc_program* prog;
+  void* trig_dev;
+  const float* umat_dev;
+  int H, n, n_theta;
+  float* params_dev; float* m_dev; float* v_dev; void* opt_state_dev;
+  float* hist_dev; int hist_cap;
+  const float* X_res_dev; int64_t B_res;
+  const float* X_val_dev; int64_t B_val;   /* IC points first, then BC points */
+  float* ajets_res_dev; float* qjets_res_dev; float* qbar_res_dev; float* abar_res_dev; /* 6*n*B_res each */
+  float* ajets_val_dev; float* qjets_val_dev; float* qbar_val_dev; float* abar_val_dev; /* n*B_val each */
+  float* part_dev; int64_t part_stride; int64_t part_rows_cap;
+  float* flat_dev;                                                                       /* NP+3 */
+  qc_pde pde;
+  qc_opt_hyper hyper;
+} qc_step_desc;
+
+#define QC_PHASE_GRADS 1
+#define QC_PHASE_UPDATE 2
+int qc_fused_pinn_residual_step(const qc_step_desc* desc, int phases, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCPINN_HIP_H */

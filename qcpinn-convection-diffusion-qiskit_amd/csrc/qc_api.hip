@@ -1,0 +1,273 @@
+// extern "C" entry points of libqcpinn_hip.so (declared in include/qcpinn_hip.h).
+// Argument checking happens here, once, on the host: the kernels assume validated shapes.
+#include "qc_internal.h"
+#include "../../include/qcpinn_hip.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static_assert(sizeof(QcPde) == sizeof(qc_pde), "qc_pde layout");
+static_assert(sizeof(QcOptHyper) == sizeof(qc_opt_hyper), "qc_opt_hyper layout");
+
+static thread_local int g_last_hip = 0;
+
+static inline int hip_fail(hipError_t e) {
+  g_last_hip = (int)e;
+  return QC_ERR_HIP;
+}
+static inline int after_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? QC_OK : hip_fail(e);
+}
+
+static QcLayout make_layout(int H, int n, int n_theta) { return qc_layout(H, n, n_theta); }
+static QcPde to_pde(const qc_pde* p) {
+  QcPde q;
+  memcpy(&q, p, sizeof(q));
+  return q;
+}
+
+// Which kernel family serves n qubits: registers (one lane per statevector) up to 5,
+// lanes-as-amplitudes above.
+static inline bool use_reg(int n) { return n >= 2 && n <= 5; }
+static inline bool use_wave(int n) { return n >= 1 && n <= 10; }
+
+extern "C" {
+
+int qc_version(void) { return QC_ABI_VERSION; }
+
+const char* qc_error_string(int code) {
+  switch (code) {
+    case QC_OK: return "ok";
+    case QC_ERR_ARG: return "invalid argument";
+    case QC_ERR_UNSUPPORTED: return "unsupported shape (qubit count / hidden width outside the built kernels)";
+    case QC_ERR_HIP: return "HIP runtime error (see qc_last_hip_error)";
+    case QC_ERR_ALLOC: return "allocation failed";
+    default: return "unknown error";
+  }
+}
+
+int qc_last_hip_error(void) { return g_last_hip; }
+
+int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_params, qc_program** out) {
+  if (!rows || !out || n_gates <= 0 || n_qubits < 1 || n_qubits > 24 || n_params < 0) return QC_ERR_ARG;
+  QcGate* h = (QcGate*)malloc(sizeof(QcGate) * n_gates);
+  if (!h) return QC_ERR_ALLOC;
+  int n_u4 = 0;
+  for (int g = 0; g < n_gates; ++g) {
+    const int op = rows[4 * g], a = rows[4 * g + 1], b = rows[4 * g + 2], slot = rows[4 * g + 3];
+    bool ok = op >= QC_RX && op <= QC_U4 && a >= 0 && a < n_qubits;
+    const bool two = (op == QC_CNOT || op == QC_CRX || op == QC_CRZ || op == QC_U4);
+    if (two) ok = ok && b >= 0 && b < n_qubits && b != a;
+    const bool par = (op == QC_RX || op == QC_RY || op == QC_RZ || op == QC_CRX || op == QC_CRZ);
+    if (par) ok = ok && slot >= 0 && slot < n_params;
+    if (op == QC_U4) {  // the kernels hard-wire slot 0 = wires [0,1], slot 1 = wires [2,3]
+      ok = ok && n_qubits >= 4 && ((slot == 0 && a == 0 && b == 1) || (slot == 1 && a == 2 && b == 3));
+      ++n_u4;
+    }
+    if (!ok) {
+      free(h);
+      return QC_ERR_ARG;
+    }
+    h[g].op = op;
+    h[g].ba = n_qubits - 1 - a;
+    h[g].bb = two ? n_qubits - 1 - b : -1;
+    h[g].slot = (par || op == QC_U4) ? slot : -1;
+  }
+  qc_program* p = (qc_program*)malloc(sizeof(qc_program));
+  if (!p) {
+    free(h);
+    return QC_ERR_ALLOC;
+  }
+  p->n_qubits = n_qubits; p->n_gates = n_gates; p->n_params = n_params; p->n_u4 = n_u4;
+  p->h_gates = h; p->d_gates = nullptr;
+  hipError_t e = hipMalloc((void**)&p->d_gates, sizeof(QcGate) * n_gates);
+  if (e == hipSuccess) e = hipMemcpy(p->d_gates, h, sizeof(QcGate) * n_gates, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    if (p->d_gates) (void)hipFree(p->d_gates);
+    free(h);
+    free(p);
+    return hip_fail(e);
+  }
+  *out = p;
+  return QC_OK;
+}
+
+int qc_program_destroy(qc_program* p) {
+  if (!p) return QC_ERR_ARG;
+  if (p->d_gates) (void)hipFree(p->d_gates);
+  free(p->h_gates);
+  free(p);
+  return QC_OK;
+}
+
+size_t qc_trig_bytes(const qc_program* p) { return p ? sizeof(QcTrig) * (size_t)p->n_gates : 0; }
+
+int qc_prepare_gates(const qc_program* p, const float* theta, void* trig, void* stream) {
+  if (!p || !trig || (p->n_params > 0 && !theta)) return QC_ERR_ARG;
+  qc_opt_prep_trig(p, theta, (QcTrig*)trig, (hipStream_t)stream);
+  return after_launch();
+}
+
+static int check_circuit(const qc_program* p, const void* trig, const float* umat, int64_t B) {
+  if (!p || !trig || B <= 0) return QC_ERR_ARG;
+  if (p->n_u4 > 0 && !umat) return QC_ERR_ARG;
+  if (!use_reg(p->n_qubits) && !use_wave(p->n_qubits)) return QC_ERR_UNSUPPORTED;
+  return QC_OK;
+}
+
+int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, const float* angles,
+                      float* expval, int64_t B, void* stream) {
+  int rc = check_circuit(p, trig, umat, B);
+  if (rc) return rc;
+  if (!angles || !expval) return QC_ERR_ARG;
+  rc = use_reg(p->n_qubits)
+           ? qc_reg_value_fwd(p, (const QcTrig*)trig, umat, angles, expval, B, (hipStream_t)stream)
+           : qc_wave_value_fwd(p, (const QcTrig*)trig, umat, angles, expval, B, (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+int qc_backward_expval(const qc_program* p, const void* trig, const float* umat, const float* angles,
+                       const float* cot, float* d_angles, float* part, int64_t part_stride, int64_t row0,
+                       int64_t B, void* stream) {
+  int rc = check_circuit(p, trig, umat, B);
+  if (rc) return rc;
+  if (!angles || !cot || !d_angles || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
+  rc = use_reg(p->n_qubits)
+           ? qc_reg_value_bwd(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B,
+                              (hipStream_t)stream)
+           : qc_wave_value_bwd(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B,
+                               (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+int qc_forward_jets(const qc_program* p, const void* trig, const float* umat, const float* ajets, float* qjets,
+                    int64_t B, void* stream) {
+  int rc = check_circuit(p, trig, umat, B);
+  if (rc) return rc;
+  if (!ajets || !qjets) return QC_ERR_ARG;
+  rc = use_reg(p->n_qubits)
+           ? qc_reg_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, (hipStream_t)stream)
+           : qc_wave_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+int qc_backward_jets(const qc_program* p, const void* trig, const float* umat, const float* ajets,
+                     const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
+                     void* stream) {
+  int rc = check_circuit(p, trig, umat, B);
+  if (rc) return rc;
+  if (!ajets || !qbar || !abar || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
+  rc = use_reg(p->n_qubits)
+           ? qc_reg_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B,
+                             (hipStream_t)stream)
+           : qc_wave_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B,
+                              (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+static int check_mlp(int H, int n, int n_theta, int64_t B, int nch) {
+  if (H < 1 || H > 1024 || n < 1 || n > 16 || n_theta < 0 || B <= 0 || (nch != 1 && nch != 6)) return QC_ERR_ARG;
+  return QC_OK;
+}
+
+int qc_pre_forward(const float* X, const float* prm, int H, int n, int n_theta, float* ajets, int64_t B, int nch,
+                   void* stream) {
+  int rc = check_mlp(H, n, n_theta, B, nch);
+  if (rc) return rc;
+  if (!X || !prm || !ajets) return QC_ERR_ARG;
+  rc = qc_mlp_pre_fwd(X, prm, make_layout(H, n, n_theta), ajets, B, nch, (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+int qc_pre_backward(const float* X, const float* prm, int H, int n, int n_theta, const float* abar, float* part,
+                    int64_t part_stride, int64_t row0, int64_t B, int nch, void* stream) {
+  int rc = check_mlp(H, n, n_theta, B, nch);
+  if (rc) return rc;
+  const QcLayout L = make_layout(H, n, n_theta);
+  if (!X || !prm || !abar || !part || part_stride < L.NP || row0 < 0) return QC_ERR_ARG;
+  rc = qc_mlp_pre_bwd(X, prm, L, abar, part, part_stride, row0, B, nch, (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+int qc_post(int mode, const float* X, const float* prm, int H, int n, int n_theta, const qc_pde* pde,
+            const float* qjets, float* out_u, float* out_res, const float* in_ubar, const float* in_rbar,
+            float* qbar, float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, void* stream) {
+  int rc = check_mlp(H, n, n_theta, B, nch);
+  if (rc) return rc;
+  const QcLayout L = make_layout(H, n, n_theta);
+  if (mode < 0 || mode > 2 || !X || !prm || !pde || !qjets) return QC_ERR_ARG;
+  if (mode >= 1 && (!qbar || !part || row0 < 0 || part_stride < L.NP + (mode == 2 ? 3 : 0))) return QC_ERR_ARG;
+  rc = qc_mlp_post(mode, X, prm, L, to_pde(pde), qjets, out_u, out_res, in_ubar, in_rbar, qbar, part, part_stride,
+                   row0, B, nch, (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+int qc_reduce_rows(const float* part, int64_t rows, int64_t stride, int ncols, float* out, void* stream) {
+  if (!part || !out || rows <= 0 || ncols <= 0 || stride < ncols) return QC_ERR_ARG;
+  qc_opt_reduce_rows(part, rows, stride, ncols, out, (hipStream_t)stream);
+  return after_launch();
+}
+
+int qc_adam_step(float* flat, int NP, float* prm, float* m, float* v, void* state, const qc_opt_hyper* hp,
+                 float* hist, int hist_cap, const qc_program* prog, int theta_off, void* trig, void* stream) {
+  if (!flat || NP <= 0 || !prm || !m || !v || !state || !hp) return QC_ERR_ARG;
+  if (prog && (!trig || theta_off < 0 || theta_off + prog->n_params > NP)) return QC_ERR_ARG;
+  QcOptHyper h;
+  memcpy(&h, hp, sizeof(h));
+  qc_opt_adam(flat, NP, prm, m, v, (QcOptState*)state, h, hist, hist_cap, prog, theta_off, (QcTrig*)trig,
+              (hipStream_t)stream);
+  return after_launch();
+}
+
+int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream) {
+  if (!d || !d->prog || !d->trig_dev || !d->params_dev || !d->part_dev || !d->flat_dev) return QC_ERR_ARG;
+  const int n = d->n, H = d->H;
+  if (d->prog->n_qubits != n || d->prog->n_params != d->n_theta) return QC_ERR_ARG;
+  int rc = check_mlp(H, n, d->n_theta, d->B_res > 0 ? d->B_res : 1, 6);
+  if (rc) return rc;
+  const QcLayout L = make_layout(H, n, d->n_theta);
+  const int64_t rows_res = d->B_res > 0 ? qc_ceil_div(d->B_res, 64) : 0;
+  const int64_t rows_val = d->B_val > 0 ? qc_ceil_div(d->B_val, 64) : 0;
+  const int64_t rows = rows_res + rows_val;
+  if (rows <= 0 || rows > d->part_rows_cap || d->part_stride < L.NP + 3) return QC_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const QcTrig* trig = (const QcTrig*)d->trig_dev;
+  const QcPde pde = to_pde(&d->pde);
+
+  if (phases & QC_PHASE_GRADS) {
+    if (d->B_res > 0) {
+      if (!d->X_res_dev || !d->ajets_res_dev || !d->qjets_res_dev || !d->qbar_res_dev || !d->abar_res_dev)
+        return QC_ERR_ARG;
+      if ((rc = qc_pre_forward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->ajets_res_dev, d->B_res, 6, st))) return rc;
+      if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, st))) return rc;
+      if ((rc = qc_post(2, d->X_res_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_res_dev, nullptr, nullptr,
+                        nullptr, nullptr, d->qbar_res_dev, d->part_dev, d->part_stride, 0, d->B_res, 6, st))) return rc;
+      if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
+                                 d->part_dev + L.oTh, d->part_stride, 0, d->B_res, st))) return rc;
+      if ((rc = qc_pre_backward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->abar_res_dev, d->part_dev,
+                                d->part_stride, 0, d->B_res, 6, st))) return rc;
+    }
+    if (d->B_val > 0) {
+      if (!d->X_val_dev || !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
+        return QC_ERR_ARG;
+      if ((rc = qc_pre_forward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->ajets_val_dev, d->B_val, 1, st))) return rc;
+      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qjets_val_dev, d->B_val, st))) return rc;
+      if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev, nullptr, nullptr,
+                        nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride, rows_res, d->B_val, 1, st))) return rc;
+      if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev,
+                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, st))) return rc;
+      if ((rc = qc_pre_backward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->abar_val_dev, d->part_dev,
+                                d->part_stride, rows_res, d->B_val, 1, st))) return rc;
+    }
+    if ((rc = qc_reduce_rows(d->part_dev, rows, d->part_stride, L.NP + 3, d->flat_dev, st))) return rc;
+  }
+  if (phases & QC_PHASE_UPDATE) {
+    if (!d->m_dev || !d->v_dev || !d->opt_state_dev) return QC_ERR_ARG;
+    if ((rc = qc_adam_step(d->flat_dev, L.NP, d->params_dev, d->m_dev, d->v_dev, d->opt_state_dev, &d->hyper,
+                           d->hist_dev, d->hist_cap, d->prog, L.oTh, d->trig_dev, st))) return rc;
+  }
+  return QC_OK;
+}
+
+}  // extern "C"

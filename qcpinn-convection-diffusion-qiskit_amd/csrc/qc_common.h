@@ -1,0 +1,66 @@
+// Shared definitions for the gfx950 QCPINN kernels (device + host side of the C-ABI library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- error codes returned by every extern "C" entry point (0 = ok, negative = failure)
+#define QC_OK 0
+#define QC_ERR_ARG (-1)          // null pointer / bad size / unsupported combination
+#define QC_ERR_UNSUPPORTED (-2)  // shape outside what the kernels are built for
+#define QC_ERR_HIP (-3)          // a HIP runtime call failed (see qc_last_hip_error)
+#define QC_ERR_ALLOC (-4)
+
+// ---- gate opcodes: must match circuits.py
+enum QcOp : int { QC_RX = 0, QC_RY = 1, QC_RZ = 2, QC_H = 3, QC_CNOT = 4, QC_CRX = 5, QC_CRZ = 6, QC_U4 = 7 };
+
+// One gate of the device-resident program.  `ba`/`bb` are BIT positions of the amplitude
+// index (bit = n-1-wire: wire 0 is the most significant bit), not wires.
+struct QcGate {
+  int op;
+  int ba;    // target bit (1q), control bit (controlled), high bit of the 4x4 index (U4)
+  int bb;    // target bit (controlled), low bit of the 4x4 index (U4), -1 otherwise
+  int slot;  // flat parameter index, U4 slot, or -1
+};
+
+// Per-gate trig table entry, rebuilt on device every time the parameters change.
+struct QcTrig {
+  float c;  // cos(theta/2)
+  float s;  // sin(theta/2)
+};
+
+struct qc_program {
+  int n_qubits;
+  int n_gates;
+  int n_params;
+  int n_u4;
+  QcGate* d_gates;  // device
+  QcGate* h_gates;  // host copy
+};
+
+// Channel numbering of the derivative ("jet") channels carried through the network:
+// 0 value, 1 d/dt, 2 d/dx, 3 d/dy, 4 d2/dx2, 5 d2/dy2.
+#define QC_NCH 6
+
+#define QC_WAVE 64
+
+static inline int qc_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------ wave-level reductions
+// Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic).  The total is
+// valid in lane 63 (and only there).
+__device__ __forceinline__ float qc_wave_sum_to_lane63(float v) {
+  // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror, row_bcast15, row_bcast31
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
+  return v;
+}
+
+// Sum over the wave, result broadcast to every lane (uniform value).
+__device__ __forceinline__ float qc_wave_sum(float v) {
+  v = qc_wave_sum_to_lane63(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}

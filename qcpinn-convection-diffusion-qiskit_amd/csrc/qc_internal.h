@@ -1,0 +1,82 @@
+// Internal structs and launcher prototypes shared by the translation units of libqcpinn_hip.so.
+#pragma once
+#include "qc_common.h"
+
+struct QcLayout {  // column offsets of the flat parameter / gradient vector
+  int H, n;
+  int oW1, ob1, oW2, ob2, oW3, ob3, oW4, ob4, oTh, NP;
+};
+
+inline QcLayout qc_layout(int H, int n, int n_theta) {
+  QcLayout L;
+  L.H = H;
+  L.n = n;
+  L.oW1 = 0;
+  L.ob1 = 3 * H;
+  L.oW2 = L.ob1 + H;
+  L.ob2 = L.oW2 + n * H;
+  L.oW3 = L.ob2 + n;
+  L.ob3 = L.oW3 + H * n;
+  L.oW4 = L.ob3 + H;
+  L.ob4 = L.oW4 + H;
+  L.oTh = L.ob4 + 1;
+  L.NP = L.oTh + n_theta;
+  return L;
+}
+
+struct QcPde {  // == qc_pde of the public header
+  float D, vx, vy;
+  float w_res;
+  float inv_n_res;
+  float w_val_a, w_val_b;
+  float inv_n_a, inv_n_b;
+  int64_t n_seg_a;
+};
+
+// device-resident optimiser state (64-byte record; host reads it back on demand)
+struct QcOptState {
+  float lr;
+  float best;
+  int num_bad;
+  int step;  // number of Adam steps taken
+  float last_loss;
+  float last_norm;
+  float loss_parts[3];
+  int pad[7];
+};
+
+struct QcOptHyper {  // == qc_opt_hyper of the public header
+  double beta1, beta2;  // kept in double: torch forms the bias corrections in Python floats
+  float eps, max_norm;
+  float sched_factor, sched_threshold, sched_min_lr, sched_eps;
+  int sched_patience;
+  float w_res, w_bc, w_ic;  // loss = w_res*L_r + w_bc*L_bc + w_ic*L_ic   (2, 4, 2)
+};
+
+// ---- launchers, one group per .hip file
+int qc_reg_value_fwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, float* expval,
+                     int64_t B, hipStream_t);
+int qc_reg_value_bwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, const float* cot,
+                     float* d_angles, float* part, int64_t part_stride, int64_t row0, int64_t B, hipStream_t);
+int qc_reg_jets_fwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, float* qjets,
+                    int64_t B, hipStream_t);
+int qc_reg_jets_bwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, const float* qbar,
+                    float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, hipStream_t);
+int qc_wave_value_fwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, float* expval,
+                      int64_t B, hipStream_t);
+int qc_wave_value_bwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, const float* cot,
+                      float* d_angles, float* part, int64_t part_stride, int64_t row0, int64_t B, hipStream_t);
+int qc_wave_jets_fwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, float* qjets,
+                     int64_t B, hipStream_t);
+int qc_wave_jets_bwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, const float* qbar,
+                     float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, hipStream_t);
+int qc_mlp_pre_fwd(const float* X, const float* prm, QcLayout L, float* ajets, int64_t B, int nch, hipStream_t);
+int qc_mlp_pre_bwd(const float* X, const float* prm, QcLayout L, const float* abar, float* part,
+                   int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t);
+int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pde, const float* qjets,
+                float* out_u, float* out_res, const float* in_ubar, const float* in_rbar, float* qbar,
+                float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t);
+int qc_opt_reduce_rows(const float* part, int64_t rows, int64_t stride, int ncols, float* out, hipStream_t);
+int qc_opt_adam(float* flat, int NP, float* prm, float* m, float* v, QcOptState* state, QcOptHyper hp,
+                float* hist, int hist_cap, const qc_program* pg, int theta_off, QcTrig* trig, hipStream_t);
+int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t);

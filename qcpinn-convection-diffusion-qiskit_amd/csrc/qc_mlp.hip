@@ -1,0 +1,411 @@
+// Classical pre/post networks of DVPDESolver with forward-mode derivative channels, the PDE
+// residual, the weighted MSE loss and their reverse pass.
+//
+// Replaces, for the fused path, what the reference runs as torch modules + 5 autograd.grad calls
+// + loss.backward():
+//   pre  : Linear(3,H) -> Tanh -> Linear(H,n)      nn/DVPDESolver.py:37-43
+//   post : Linear(n,H) -> Tanh -> Linear(H,1)      nn/DVPDESolver.py:45-51
+//   residual = u_t + v_x u_x + v_y u_y - D (u_xx + u_yy)          nn/pde.py:53-72
+//   targets u(t,x,y), r(t,x,y) (incl. the -400 constant)           data/diffusion_dataset.py:20-38
+//   loss parts = MSE(residual, r), MSE(u_bc, u), MSE(u_ic, u)      trainer/diffusion_train.py:44-47
+//
+// Parameters live in ONE flat fp32 buffer in torch's model.parameters() order:
+//   W1[H][3] b1[H] W2[n][H] b2[n] | W3[H][n] b3[H] W4[H] b4 | theta[L*P]
+// Gradients leave every kernel as one "partial row" per block ([rows][stride] buffer, same column
+// order, 3 extra columns for the loss sums); qc_optim.hip reduces rows in a fixed order, so the
+// result is bit-reproducible (no float atomics).
+//
+// NCH = 6 : residual points, channels {value, d/dt, d/dx, d/dy, d2/dx2, d2/dy2};
+// NCH = 1 : boundary / initial-condition points, value channel only.
+#include "qc_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float qc_tanh(float x) { return tanhf(x); }
+
+// analytic solution and forcing term, data/diffusion_dataset.py:20-38
+__device__ __forceinline__ float analytic_u(float t, float x, float y) {
+  const float dx = x - 0.5f, dy = y - 0.5f;
+  return expf(-100.f * (dx * dx + dy * dy)) * expf(-t);
+}
+__device__ __forceinline__ float analytic_r(float t, float x, float y, float D, float vx, float vy) {
+  const float u = analytic_u(t, x, y);
+  const float dx = x - 0.5f, dy = y - 0.5f;
+  const float ut = -u, ux = -200.f * dx * u, uy = -200.f * dy * u;
+  const float uxx = (40000.f * dx * dx - 400.f) * u;  // the reference's constant (:31-34)
+  const float uyy = (40000.f * dy * dy - 400.f) * u;
+  return ut + vx * ux + vy * uy - D * (uxx + uyy);
+}
+
+// ================================================================== pre network, forward jets
+// lane = collocation point; loop over hidden units with wave-uniform (scalar) weights.
+template <int N, int NCH>
+__global__ void __launch_bounds__(256) k_pre_fwd(const float* __restrict__ X, const float* __restrict__ prm,
+                                                 QcLayout L, float* __restrict__ ajets, int64_t B) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t pc = p < B ? p : B - 1;
+  const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
+  float acc[NCH][N];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[c][i] = 0.f;
+  const float* W1 = prm + L.oW1;
+  const float* b1 = prm + L.ob1;
+  const float* W2 = prm + L.oW2;
+  for (int m = 0; m < L.H; ++m) {
+    const float w0 = W1[3 * m], w1 = W1[3 * m + 1], w2 = W1[3 * m + 2];
+    const float h = fmaf(w0, t, fmaf(w1, x, fmaf(w2, y, b1[m])));
+    const float z = qc_tanh(h);
+    float zc[NCH];
+    zc[0] = z;
+    if constexpr (NCH == 6) {
+      const float d1 = 1.f - z * z, d2 = -2.f * z * d1;
+      zc[1] = d1 * w0;
+      zc[2] = d1 * w1;
+      zc[3] = d1 * w2;
+      zc[4] = d2 * w1 * w1;
+      zc[5] = d2 * w2 * w2;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float wi = W2[i * L.H + m];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c][i] = fmaf(wi, zc[c], acc[c][i]);
+    }
+  }
+  if (p < B) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      ajets[(int64_t)i * B + p] = acc[0][i] + prm[L.ob2 + i];
+#pragma unroll
+      for (int c = 1; c < NCH; ++c) ajets[((int64_t)c * N + i) * B + p] = acc[c][i];
+    }
+  }
+}
+
+// ================================================================== pre network, reverse pass
+// lane = hidden unit (each lane owns one row of W1 / column of W2, so weight gradients need no
+// cross-lane reduction); the block walks its tile of 64 points, whose coordinates and angle-jet
+// cotangents are staged in LDS and read as broadcasts.
+template <int N, int NCH>
+__global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+                          const float* __restrict__ abar, float* __restrict__ part, int64_t part_stride,
+                          int64_t row0, int64_t B) {
+  __shared__ float sX[3][64];
+  __shared__ float sA[NCH * N][64];
+  const int64_t base = (int64_t)blockIdx.x * 64;
+  const int cnt = (int)((B - base) < 64 ? (B - base) : 64);
+  for (int i = threadIdx.x; i < 64 * 3; i += blockDim.x) {
+    const int pp = i / 3, k = i % 3;
+    sX[k][pp] = pp < cnt ? X[(base + pp) * 3 + k] : 0.f;
+  }
+  for (int i = threadIdx.x; i < NCH * N * 64; i += blockDim.x) {
+    const int f = i >> 6, pp = i & 63;
+    sA[f][pp] = pp < cnt ? abar[(int64_t)f * B + base + pp] : 0.f;
+  }
+  __syncthreads();
+
+  const int m = threadIdx.x;
+  float* row = part + (row0 + blockIdx.x) * part_stride;
+  if (m < L.H) {
+    const float w0 = prm[L.oW1 + 3 * m], w1 = prm[L.oW1 + 3 * m + 1], w2 = prm[L.oW1 + 3 * m + 2];
+    const float bb = prm[L.ob1 + m];
+    float w2c[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w2c[i] = prm[L.oW2 + i * L.H + m];
+    float gW1[3] = {0.f, 0.f, 0.f}, gb1 = 0.f, gW2[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) gW2[i] = 0.f;
+    for (int pp = 0; pp < cnt; ++pp) {
+      const float t = sX[0][pp], x = sX[1][pp], y = sX[2][pp];
+      const float h = fmaf(w0, t, fmaf(w1, x, fmaf(w2, y, bb)));
+      const float z = qc_tanh(h);
+      const float d1 = 1.f - z * z;
+      float zb[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s = fmaf(w2c[i], sA[c * N + i][pp], s);
+        zb[c] = s;
+      }
+      if constexpr (NCH == 6) {
+        const float d2 = -2.f * z * d1;
+        const float d3 = -2.f * (d1 * d1 + z * d2);
+        const float zc[6] = {z, d1 * w0, d1 * w1, d1 * w2, d2 * w1 * w1, d2 * w2 * w2};
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          float s = gW2[i];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) s = fmaf(sA[c * N + i][pp], zc[c], s);
+          gW2[i] = s;
+        }
+        const float hb = zb[0] * d1 + (zb[1] * w0 + zb[2] * w1 + zb[3] * w2) * d2 +
+                         (zb[4] * w1 * w1 + zb[5] * w2 * w2) * d3;
+        gW1[0] += hb * t + zb[1] * d1;
+        gW1[1] += hb * x + zb[2] * d1 + 2.f * zb[4] * d2 * w1;
+        gW1[2] += hb * y + zb[3] * d1 + 2.f * zb[5] * d2 * w2;
+        gb1 += hb;
+      } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) gW2[i] = fmaf(sA[i][pp], z, gW2[i]);
+        const float hb = zb[0] * d1;
+        gW1[0] += hb * t;
+        gW1[1] += hb * x;
+        gW1[2] += hb * y;
+        gb1 += hb;
+      }
+    }
+    row[L.oW1 + 3 * m] = gW1[0];
+    row[L.oW1 + 3 * m + 1] = gW1[1];
+    row[L.oW1 + 3 * m + 2] = gW1[2];
+    row[L.ob1 + m] = gb1;
+#pragma unroll
+    for (int i = 0; i < N; ++i) row[L.oW2 + i * L.H + m] = gW2[i];
+  }
+  if (m < N) {  // b2 only feeds the value channel
+    float s = 0.f;
+    for (int pp = 0; pp < cnt; ++pp) s += sA[m][pp];
+    row[L.ob2 + m] = s;
+  }
+}
+
+// ================================================================== post network + PDE + loss
+// lane = collocation point, one wave per block (a block owns one partial row).
+// MODE 0: forward only  -> u, residual
+// MODE 1: reverse only, cotangents (ubar, rbar) read from memory (autograd path)
+// MODE 2: forward + loss + reverse in one pass (training step)
+template <int N, int NCH, int MODE>
+__global__ void __launch_bounds__(64) k_post(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+                                             QcPde pde, const float* __restrict__ qjets,
+                                             float* __restrict__ out_u, float* __restrict__ out_res,
+                                             const float* __restrict__ in_ubar, const float* __restrict__ in_rbar,
+                                             float* __restrict__ qbar, float* __restrict__ part,
+                                             int64_t part_stride, int64_t row0, int64_t B) {
+  const int lane = threadIdx.x;
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+  float q[NCH][N];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[c][i] = qjets[((int64_t)c * N + i) * B + pc];
+  const float* W3 = prm + L.oW3;
+  const float* b3 = prm + L.ob3;
+  const float* W4 = prm + L.oW4;
+
+  float ub[NCH];  // cotangents of the u channels
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) ub[c] = 0.f;
+
+  if constexpr (MODE == 0 || MODE == 2) {
+    float u[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) u[c] = 0.f;
+    for (int m = 0; m < L.H; ++m) {
+      float g[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float s = (c == 0) ? b3[m] : 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s = fmaf(W3[m * N + i], q[c][i], s);
+        g[c] = s;
+      }
+      const float z = qc_tanh(g[0]);
+      const float w4 = W4[m];
+      u[0] = fmaf(w4, z, u[0]);
+      if constexpr (NCH == 6) {
+        const float d1 = 1.f - z * z, d2 = -2.f * z * d1;
+        u[1] = fmaf(w4, d1 * g[1], u[1]);
+        u[2] = fmaf(w4, d1 * g[2], u[2]);
+        u[3] = fmaf(w4, d1 * g[3], u[3]);
+        u[4] = fmaf(w4, d2 * g[2] * g[2] + d1 * g[4], u[4]);
+        u[5] = fmaf(w4, d2 * g[3] * g[3] + d1 * g[5], u[5]);
+      }
+    }
+    u[0] += prm[L.ob4];
+    const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
+    float res = 0.f;
+    if constexpr (NCH == 6) res = u[1] + pde.vx * u[2] + pde.vy * u[3] - pde.D * (u[4] + u[5]);
+    if constexpr (MODE == 0) {
+      if (live) {
+        if (out_u) out_u[p] = u[0];
+        if constexpr (NCH == 6)
+          if (out_res) out_res[p] = res;
+      }
+      return;
+    }
+    if constexpr (MODE == 2) {
+      float* row = part + (row0 + blockIdx.x) * part_stride;
+      if constexpr (NCH == 6) {
+        const float e = live ? res - analytic_r(t, x, y, pde.D, pde.vx, pde.vy) : 0.f;
+        const float gsc = pde.w_res * e;
+        ub[1] = gsc;
+        ub[2] = gsc * pde.vx;
+        ub[3] = gsc * pde.vy;
+        ub[4] = -pde.D * gsc;
+        ub[5] = -pde.D * gsc;
+        const float ls = qc_wave_sum_to_lane63(e * e * pde.inv_n_res);
+        if (lane == 63) {
+          row[L.NP + 0] = ls;
+          row[L.NP + 1] = 0.f;
+          row[L.NP + 2] = 0.f;
+        }
+      } else {
+        const bool seg_a = p < pde.n_seg_a;
+        const float e = live ? u[0] - analytic_u(t, x, y) : 0.f;
+        ub[0] = (seg_a ? pde.w_val_a : pde.w_val_b) * e;
+        const float la = qc_wave_sum_to_lane63(seg_a ? e * e * pde.inv_n_a : 0.f);
+        const float lb = qc_wave_sum_to_lane63(seg_a ? 0.f : e * e * pde.inv_n_b);
+        if (lane == 63) {
+          row[L.NP + 0] = 0.f;
+          row[L.NP + 1] = lb;  // column order: residual, BC, IC; segment a = IC, b = BC
+          row[L.NP + 2] = la;
+        }
+      }
+    }
+  }
+  if constexpr (MODE == 1) {
+    ub[0] = (live && in_ubar) ? in_ubar[pc] : 0.f;
+    if constexpr (NCH == 6) {
+      const float rb = (live && in_rbar) ? in_rbar[pc] : 0.f;
+      ub[1] = rb;
+      ub[2] = rb * pde.vx;
+      ub[3] = rb * pde.vy;
+      ub[4] = -pde.D * rb;
+      ub[5] = -pde.D * rb;
+    }
+  }
+
+  if constexpr (MODE == 1 || MODE == 2) {
+    float* row = part + (row0 + blockIdx.x) * part_stride;
+    float qb[NCH][N];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) qb[c][i] = 0.f;
+    for (int m = 0; m < L.H; ++m) {
+      float g[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float s = (c == 0) ? b3[m] : 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) s = fmaf(W3[m * N + i], q[c][i], s);
+        g[c] = s;
+      }
+      const float z = qc_tanh(g[0]);
+      const float w4 = W4[m];
+      const float d1 = 1.f - z * z;
+      float gb[NCH];
+      float gw4 = ub[0] * z;
+      gb[0] = ub[0] * d1;
+      if constexpr (NCH == 6) {
+        const float d2 = -2.f * z * d1;
+        const float d3 = -2.f * (d1 * d1 + z * d2);
+        const float gx2 = g[2] * g[2], gy2 = g[3] * g[3];
+        gw4 += d1 * (ub[1] * g[1] + ub[2] * g[2] + ub[3] * g[3]) + ub[4] * (d2 * gx2 + d1 * g[4]) +
+               ub[5] * (d2 * gy2 + d1 * g[5]);
+        gb[0] += d2 * (ub[1] * g[1] + ub[2] * g[2] + ub[3] * g[3]) + ub[4] * (d3 * gx2 + d2 * g[4]) +
+                 ub[5] * (d3 * gy2 + d2 * g[5]);
+        gb[1] = ub[1] * d1;
+        gb[2] = ub[2] * d1 + 2.f * ub[4] * d2 * g[2];
+        gb[3] = ub[3] * d1 + 2.f * ub[5] * d2 * g[3];
+        gb[4] = ub[4] * d1;
+        gb[5] = ub[5] * d1;
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) gb[c] *= w4;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const float w3 = W3[m * N + i];
+        float gw3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          qb[c][i] = fmaf(w3, gb[c], qb[c][i]);
+          gw3 = fmaf(gb[c], q[c][i], gw3);
+        }
+        gw3 = qc_wave_sum_to_lane63(gw3);
+        if (lane == 63) row[L.oW3 + m * N + i] = gw3;
+      }
+      const float r_b3 = qc_wave_sum_to_lane63(gb[0]);
+      const float r_w4 = qc_wave_sum_to_lane63(gw4);
+      if (lane == 63) {
+        row[L.ob3 + m] = r_b3;
+        row[L.oW4 + m] = r_w4;
+      }
+    }
+    const float r_b4 = qc_wave_sum_to_lane63(ub[0]);
+    if (lane == 63) row[L.ob4] = r_b4;
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < N; ++i) qbar[((int64_t)c * N + i) * B + p] = qb[c][i];
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launchers
+#define QC_MLP_DISPATCH(n, CALL)                                                                   \
+  switch (n) {                                                                                     \
+    case 1: { CALL(1) } break;  case 2: { CALL(2) } break;  case 3: { CALL(3) } break;             \
+    case 4: { CALL(4) } break;  case 5: { CALL(5) } break;  case 6: { CALL(6) } break;             \
+    case 7: { CALL(7) } break;  case 8: { CALL(8) } break;  case 9: { CALL(9) } break;             \
+    case 10: { CALL(10) } break; case 11: { CALL(11) } break; case 12: { CALL(12) } break;         \
+    case 13: { CALL(13) } break; case 14: { CALL(14) } break; case 15: { CALL(15) } break;         \
+    case 16: { CALL(16) } break;                                                                   \
+    default: return QC_ERR_UNSUPPORTED;                                                            \
+  }
+
+int qc_mlp_pre_fwd(const float* X, const float* prm, QcLayout L, float* ajets, int64_t B, int nch,
+                   hipStream_t st) {
+  const int grid = qc_ceil_div(B, 256);
+#define CALL(NN)                                                                                   \
+  if (nch == 6) hipLaunchKernelGGL((k_pre_fwd<NN, 6>), dim3(grid), dim3(256), 0, st, X, prm, L, ajets, B); \
+  else hipLaunchKernelGGL((k_pre_fwd<NN, 1>), dim3(grid), dim3(256), 0, st, X, prm, L, ajets, B);
+  QC_MLP_DISPATCH(L.n, CALL)
+#undef CALL
+  return QC_OK;
+}
+
+int qc_mlp_pre_bwd(const float* X, const float* prm, QcLayout L, const float* abar, float* part,
+                   int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t st) {
+  const int grid = qc_ceil_div(B, 64);
+  const int threads = 64 * qc_ceil_div(L.H > L.n ? L.H : L.n, 64);
+  if (threads > 1024) return QC_ERR_UNSUPPORTED;
+#define CALL(NN)                                                                                          \
+  if (nch == 6) hipLaunchKernelGGL((k_pre_bwd<NN, 6>), dim3(grid), dim3(threads), 0, st, X, prm, L, abar, \
+                                   part, part_stride, row0, B);                                           \
+  else hipLaunchKernelGGL((k_pre_bwd<NN, 1>), dim3(grid), dim3(threads), 0, st, X, prm, L, abar, part,    \
+                          part_stride, row0, B);
+  QC_MLP_DISPATCH(L.n, CALL)
+#undef CALL
+  return QC_OK;
+}
+
+int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pde, const float* qjets,
+                float* out_u, float* out_res, const float* in_ubar, const float* in_rbar, float* qbar,
+                float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t st) {
+  const int grid = qc_ceil_div(B, 64);
+#define LAUNCH(NN, CC, MM)                                                                              \
+  hipLaunchKernelGGL((k_post<NN, CC, MM>), dim3(grid), dim3(64), 0, st, X, prm, L, pde, qjets, out_u,    \
+                     out_res, in_ubar, in_rbar, qbar, part, part_stride, row0, B)
+#define CALL(NN)                                                         \
+  if (nch == 6) {                                                        \
+    if (mode == 0) LAUNCH(NN, 6, 0);                                     \
+    else if (mode == 1) LAUNCH(NN, 6, 1);                                \
+    else LAUNCH(NN, 6, 2);                                               \
+  } else {                                                               \
+    if (mode == 0) LAUNCH(NN, 1, 0);                                     \
+    else if (mode == 1) LAUNCH(NN, 1, 1);                                \
+    else LAUNCH(NN, 1, 2);                                               \
+  }
+  QC_MLP_DISPATCH(L.n, CALL)
+#undef CALL
+#undef LAUNCH
+  return QC_OK;
+}

@@ -1,0 +1,109 @@
+"""ctypes binding of ``libqcpinn_hip.so`` (C ABI in ``include/qcpinn_hip.h``).
+
+The library is the product: there is no CPU or torch fallback behind these calls.  Loading
+fails loudly when the shared object is missing, and every call raises ``QcError`` on a
+non-zero return code.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libqcpinn_hip.so")
+
+QC_PHASE_GRADS = 1
+QC_PHASE_UPDATE = 2
+
+# every symbol include/qcpinn_hip.h declares
+EXPORTS = (
+    "qc_version", "qc_error_string", "qc_last_hip_error", "qc_program_create", "qc_program_destroy",
+    "qc_trig_bytes", "qc_prepare_gates", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
+    "qc_backward_jets", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
+    "qc_fused_pinn_residual_step",
+)
+
+
+class QcError(RuntimeError):
+    pass
+
+
+class QcPde(C.Structure):
+    _fields_ = [("D", C.c_float), ("vx", C.c_float), ("vy", C.c_float), ("w_res", C.c_float),
+                ("inv_n_res", C.c_float), ("w_val_a", C.c_float), ("w_val_b", C.c_float),
+                ("inv_n_a", C.c_float), ("inv_n_b", C.c_float), ("n_seg_a", C.c_int64)]
+
+
+class QcOptHyper(C.Structure):
+    _fields_ = [("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_float), ("max_norm", C.c_float),
+                ("sched_factor", C.c_float), ("sched_threshold", C.c_float), ("sched_min_lr", C.c_float),
+                ("sched_eps", C.c_float), ("sched_patience", C.c_int), ("w_res", C.c_float),
+                ("w_bc", C.c_float), ("w_ic", C.c_float)]
+
+
+class QcStepDesc(C.Structure):
+    _fields_ = [
+        ("prog", C.c_void_p), ("trig_dev", C.c_void_p), ("umat_dev", C.c_void_p),
+        ("H", C.c_int), ("n", C.c_int), ("n_theta", C.c_int),
+        ("params_dev", C.c_void_p), ("m_dev", C.c_void_p), ("v_dev", C.c_void_p), ("opt_state_dev", C.c_void_p),
+        ("hist_dev", C.c_void_p), ("hist_cap", C.c_int),
+        ("X_res_dev", C.c_void_p), ("B_res", C.c_int64),
+        ("X_val_dev", C.c_void_p), ("B_val", C.c_int64),
+        ("ajets_res_dev", C.c_void_p), ("qjets_res_dev", C.c_void_p), ("qbar_res_dev", C.c_void_p),
+        ("abar_res_dev", C.c_void_p),
+        ("ajets_val_dev", C.c_void_p), ("qjets_val_dev", C.c_void_p), ("qbar_val_dev", C.c_void_p),
+        ("abar_val_dev", C.c_void_p),
+        ("part_dev", C.c_void_p), ("part_stride", C.c_int64), ("part_rows_cap", C.c_int64),
+        ("flat_dev", C.c_void_p),
+        ("pde", QcPde), ("hyper", QcOptHyper),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the in-tree library (built by ``__graft_entry__.build()`` / ``make -C csrc``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QcError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C {os.path.join(os.path.dirname(_HERE), 'csrc')}`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, fp = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
+    lib.qc_version.restype = i32
+    lib.qc_error_string.restype = C.c_char_p
+    lib.qc_error_string.argtypes = [i32]
+    lib.qc_last_hip_error.restype = i32
+    lib.qc_program_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    lib.qc_program_destroy.argtypes = [vp]
+    lib.qc_trig_bytes.restype = C.c_size_t
+    lib.qc_trig_bytes.argtypes = [vp]
+    lib.qc_prepare_gates.argtypes = [vp, fp, vp, vp]
+    lib.qc_forward_expval.argtypes = [vp, vp, fp, fp, fp, i64, vp]
+    lib.qc_backward_expval.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp]
+    lib.qc_forward_jets.argtypes = [vp, vp, fp, fp, fp, i64, vp]
+    lib.qc_backward_jets.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp]
+    lib.qc_pre_forward.argtypes = [fp, fp, i32, i32, i32, fp, i64, i32, vp]
+    lib.qc_pre_backward.argtypes = [fp, fp, i32, i32, i32, fp, fp, i64, i64, i64, i32, vp]
+    lib.qc_post.argtypes = [i32, fp, fp, i32, i32, i32, C.POINTER(QcPde), fp, fp, fp, fp, fp, fp, fp, i64, i64,
+                            i64, i32, vp]
+    lib.qc_reduce_rows.argtypes = [fp, i64, i64, i32, fp, vp]
+    lib.qc_adam_step.argtypes = [fp, i32, fp, fp, fp, vp, C.POINTER(QcOptHyper), fp, i32, vp, i32, vp, vp]
+    lib.qc_fused_pinn_residual_step.argtypes = [C.POINTER(QcStepDesc), i32, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("qc_error_string", "qc_trig_bytes"):
+            fn.restype = i32
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        lib = load()
+        msg = lib.qc_error_string(rc).decode()
+        raise QcError(f"{what or 'libqcpinn_hip'} failed: {msg} (code {rc}, hipError {lib.qc_last_hip_error()})")

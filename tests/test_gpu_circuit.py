@@ -1,0 +1,115 @@
+"""GPU parity of the variational-circuit kernels (through the C ABI) against the CPU oracle and
+the committed golden <Z> vectors.  Tolerance: 1e-5 absolute on expectation values (north_star)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, pkg
+
+from oracle import jets as ojets
+from oracle import statevector as sv
+
+pytestmark = pytest.mark.gpu
+
+TOL_Z = 1e-5
+
+
+def _circuit(ans, n, L, seed, device):
+    circuits = pkg("circuits")
+    engine = pkg("hip.engine")
+    use_haar = seed is not None and n >= 4
+    prog = circuits.build_program(ans, n, L, use_haar)
+    haar = circuits.haar_unitaries(seed, seed + 1) if use_haar else None
+    return engine.Circuit(prog, haar, device), (sv.haar_pair(seed, seed + 1) if use_haar else None)
+
+
+def _golden_cases(max_n):
+    out = []
+    for f in sorted(glob.glob(os.path.join(GOLDEN, "expval_*.npz"))):
+        z = np.load(f)
+        n = z["x"].shape[1]
+        if n <= max_n:
+            out.append(os.path.basename(f))
+    return out
+
+
+SUPPORTED_N = 5
+
+
+@pytest.mark.parametrize("fname", _golden_cases(SUPPORTED_N))
+def test_expval_matches_golden(fname, gpu_device):
+    z = np.load(os.path.join(GOLDEN, fname))
+    stem = fname[len("expval_"):-len(".npz")]
+    ans, ntag, ltag = stem.rsplit("_", 2)
+    n, L = int(ntag[1:]), int(ltag[1:])
+    seed = int(z["seed"]) if int(z["seed"]) >= 0 else None
+    circ, _ = _circuit(ans, n, L, seed, gpu_device)
+    params = torch.from_numpy(z["params"]).to(gpu_device)
+    x = torch.from_numpy(z["x"]).to(gpu_device)
+    circ.prepare(params)
+    q = circ.forward_expval(x.t().contiguous()).cpu().numpy()
+    assert q.shape == z["expval"].shape
+    assert np.abs(q - z["expval"]).max() < TOL_Z
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", [
+    ("cascade", 4, 1, 1, 200), ("layered", 4, 2, 1, 70), ("cross_mesh", 4, 1, 1, 65), ("farhi", 4, 1, 1, 64),
+    ("sim_circ_15", 4, 1, 1, 33), ("alternate", 5, 1, 1, 40), ("cascade", 3, 2, None, 50), ("cascade", 2, 1, None, 10),
+    ("cascade", 5, 1, 1, 129), ("cascade", 4, 1, None, 300),
+])
+def test_expval_vjp_matches_oracle_autograd(ans, n, L, seed, B, gpu_device):
+    """Backward of DVQuantumLayer: d/d(angles) and d/d(theta) of sum(cot * <Z>)."""
+    g = torch.Generator().manual_seed(5 + n + B)
+    circuits = pkg("circuits")
+    P = circuits.params_per_layer(ans, n)
+    params = (torch.randn(L, P, generator=g) * 0.8)
+    x = torch.randn(B, n, generator=g) * 1.1
+    cot = torch.randn(n, B, generator=g)
+    circ, haar = _circuit(ans, n, L, seed, gpu_device)
+    # oracle
+    xo = x.double().requires_grad_(True)
+    po = params.double().requires_grad_(True)
+    q = sv.circuit_expvals(xo, po, ans, n, haar)
+    (q * cot.double()).sum().backward()
+    # HIP
+    circ.prepare(params.to(gpu_device))
+    ang = x.t().contiguous().to(gpu_device)
+    qh = circ.forward_expval(ang)
+    assert (qh.cpu().double() - q.detach()).abs().max() < TOL_Z
+    d_ang, d_theta = circ.backward_expval(ang, cot.to(gpu_device))
+    assert (d_ang.t().cpu().double() - xo.grad).abs().max() < 2e-5
+    scale = max(1.0, po.grad.abs().max().item())
+    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 1e-5 * scale * np.sqrt(B)
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", [
+    ("cascade", 4, 1, 1, 70), ("layered", 4, 1, 1, 9), ("cross_mesh", 4, 1, 1, 6), ("cascade", 3, 1, None, 8),
+    ("cascade", 2, 1, None, 5), ("alternate", 5, 1, 1, 5),
+])
+def test_jets_forward_and_vjp_match_oracle(ans, n, L, seed, B, gpu_device):
+    """Six derivative channels through the circuit and their cotangents (angle jets + theta)."""
+    g = torch.Generator().manual_seed(77 + n + B)
+    circuits = pkg("circuits")
+    P = circuits.params_per_layer(ans, n)
+    params = torch.randn(L, P, generator=g) * 0.8
+    ajets = torch.randn(6, n, B, generator=g) * 0.9
+    w = torch.randn(6, n, B, generator=g)
+    circ, haar = _circuit(ans, n, L, seed, gpu_device)
+    ao = ajets.double().requires_grad_(True)
+    po = params.double().requires_grad_(True)
+    qo = ojets.qjets_from_ajets(ao, po, ans, n, haar)
+    (qo * w.double()).sum().backward()
+    circ.prepare(params.to(gpu_device))
+    aj = ajets.to(gpu_device)
+    qh = circ.forward_jets(aj)
+    err = (qh.cpu().double() - qo.detach()).abs()
+    assert err[0].max() < TOL_Z
+    assert err.max() < 1e-5 * max(1.0, qo.detach().abs().max().item())
+    abar, d_theta = circ.backward_jets(aj, w.to(gpu_device))
+    sa = max(1.0, ao.grad.abs().max().item())
+    assert (abar.cpu().double() - ao.grad).abs().max() < 2e-5 * sa
+    st = max(1.0, po.grad.abs().max().item())
+    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 2e-5 * st
