@@ -1,0 +1,246 @@
+"""``DVPDESolver`` — drop-in for the reference solver module (nn/DVPDESolver.py:9-157):
+``Linear(3,H)-Tanh-Linear(H,n)`` -> ``DVQuantumLayer`` -> ``Linear(n,H)-Tanh-Linear(H,1)`` with the
+same constructor ``(args, logger, data=None, device=None)``, attribute names, sub-module /
+state-dict names, construction order (so ``torch.manual_seed(s)`` gives the reference's initial
+weights), Adam + ReduceLROnPlateau + MSELoss members and checkpoint dictionary.
+
+The arithmetic of ``forward`` — both networks and the circuit — runs in the HIP kernels of
+``libqcpinn_hip.so``.  To let the fused training step update everything in one kernel, all
+parameters are views into ONE flat fp32 device buffer laid out in ``model.parameters()`` order.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from ..hip import engine as _engine
+from ..hip.lib import QcError
+from .DVQuantumLayer import DVQuantumLayer
+
+
+def _flat_param_list(model):
+    return [p for p in model.parameters()]
+
+
+class _ValueFn(torch.autograd.Function):
+    """X (B,3) -> u (B,1); differentiable w.r.t. the solver parameters (not w.r.t. X)."""
+
+    @staticmethod
+    def forward(ctx, X, solver, *params):
+        eng = solver._engine_for(X.device)
+        Xc = X.detach().to(torch.float32).contiguous()
+        u, _, ajets, qjets = eng.forward(Xc, 1)
+        ctx.eng, ctx.solver = eng, solver
+        ctx.save_for_backward(Xc, ajets, qjets)
+        return u
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gu):
+        Xc, ajets, qjets = ctx.saved_tensors
+        ctx.eng.refresh_gates()
+        d_flat = ctx.eng.backward(Xc, ajets, qjets, gu, None, 1)
+        return (None, None) + ctx.solver._split_flat(d_flat)
+
+
+class _ResidualFn(torch.autograd.Function):
+    """X (B,3) -> (u, residual) of the convection-diffusion operator, both (B,1)."""
+
+    @staticmethod
+    def forward(ctx, X, solver, pde, *params):
+        eng = solver._engine_for(X.device)
+        eng.D, eng.vx, eng.vy = pde
+        Xc = X.detach().to(torch.float32).contiguous()
+        u, res, ajets, qjets = eng.forward(Xc, _engine.NCH)
+        ctx.eng, ctx.solver, ctx.pde = eng, solver, pde
+        ctx.save_for_backward(Xc, ajets, qjets)
+        return u, res
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gu, gres):
+        Xc, ajets, qjets = ctx.saved_tensors
+        eng = ctx.eng
+        eng.D, eng.vx, eng.vy = ctx.pde
+        eng.refresh_gates()
+        d_flat = eng.backward(Xc, ajets, qjets, gu, gres, _engine.NCH)
+        return (None, None, None) + ctx.solver._split_flat(d_flat)
+
+
+class DVPDESolver(nn.Module):
+    def __init__(self, args, logger, data=None, device=None):
+        super().__init__()
+        self.logger = logger
+        self.device = device
+        self.args = args
+        self.data = data
+        self.batch_size = self.args["batch_size"]
+        self.num_qubits = self.args["num_qubits"]
+        self.epochs = self.args["epochs"]
+        self.optimizer = None
+        self.scheduler = None
+        self.loss_history = []
+        self.encoding = self.args.get("encoding", "angle")
+        self.draw_quantum_circuit_flag = True
+        self.classic_network = self.args["classic_network"]
+        self.total_training_time = 0
+        self.total_memory_peak = 0
+        if self.classic_network[0] != 3 or self.classic_network[-1] != 1:
+            raise ValueError("the convection-diffusion DV path maps (t, x, y) -> u: classic_network must be "
+                             f"[3, H, 1], got {self.classic_network}")
+        hidden = self.classic_network[-2]
+
+        # same construction order as the reference => same RNG consumption (nn/DVPDESolver.py:28-57)
+        self.preprocessor = nn.Sequential(nn.Linear(self.classic_network[0], hidden), nn.Tanh(),
+                                          nn.Linear(hidden, self.num_qubits))
+        self.postprocessor = nn.Sequential(nn.Linear(self.num_qubits, hidden), nn.Tanh(),
+                                           nn.Linear(hidden, self.classic_network[-1]))
+        self.activation = nn.Tanh()
+        self.quantum_layer = DVQuantumLayer(self.args)
+
+        self.optimizer = torch.optim.Adam(filter(lambda p: p.requires_grad, self.parameters()), lr=self.args["lr"])
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=0.9,
+                                                                    patience=1000)
+        self.loss_fn = torch.nn.MSELoss()
+        self.log_path = self.logger.get_output_dir() if self.logger is not None else "."
+        for layer in self.preprocessor:          # only the preprocessor is re-initialised (:69-76)
+            if isinstance(layer, nn.Linear):
+                nn.init.xavier_normal_(layer.weight)
+                nn.init.zeros_(layer.bias)
+
+        self._flat = None
+        self._engines = {}
+        self._fused_opt = None
+        target = self._resolve_device(device)
+        if target is not None:
+            self.device = target         # samplers of reference-style loops read model.device
+            self._pack(target)
+
+    # ------------------------------------------------------------------ device / flat storage
+    @staticmethod
+    def _resolve_device(device):
+        """None (what the stock reference scripts end up passing) means "the GPU if
+        there is one"; construction alone never needs a GPU."""
+        if device is None:
+            return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+        device = torch.device(device)
+        if device.type == "cuda" and not torch.cuda.is_available():
+            return None
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        return device
+
+    @property
+    def hidden_width(self) -> int:
+        return self.classic_network[-2]
+
+    def _pack(self, device) -> None:
+        """Move every parameter into one flat buffer on ``device`` and re-point the Parameters at
+        views of it (``model.parameters()`` order = kernel layout, see hip/engine.param_layout)."""
+        plist = _flat_param_list(self)
+        flat = torch.cat([p.detach().reshape(-1).to(device=device, dtype=torch.float32) for p in plist])
+        off = 0
+        for p in plist:
+            k = p.numel()
+            p.data = flat[off:off + k].view(p.shape)
+            off += k
+        self._flat = flat
+        self._engines = {}
+        self._fused_opt = None
+
+    def _packed_ok(self) -> bool:
+        if self._flat is None:
+            return False
+        off = 0
+        for p in _flat_param_list(self):
+            if p.device != self._flat.device or p.data_ptr() != self._flat.data_ptr() + 4 * off:
+                return False
+            off += p.numel()
+        return off == self._flat.numel()
+
+    def _engine_for(self, device) -> "_engine.SolverEngine":
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise QcError(f"DVPDESolver computes on the GPU only (HIP kernels, no CPU fallback); input is on {device}")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if not self._packed_ok() or self._flat.device != device:
+            self._pack(device)           # e.g. after model.to(...), load_state_dict into new tensors
+        key = device.index
+        if key not in self._engines:
+            circ = self.quantum_layer._circuit_for(device)
+            self._engines[key] = _engine.SolverEngine(circ, self.hidden_width, self._flat)
+        return self._engines[key]
+
+    def _split_flat(self, d_flat):
+        out, off = [], 0
+        for p in _flat_param_list(self):
+            k = p.numel()
+            out.append(d_flat[off:off + k].view(p.shape))
+            off += k
+        return tuple(out)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        try:
+            if x.dim() != 2:
+                raise ValueError(f"Expected 2D input tensor, got shape {x.shape}")
+            if self.draw_quantum_circuit_flag:
+                self.draw_quantum_circuit(x)
+                self.draw_quantum_circuit_flag = False
+            self._engine_for(x.device)
+            return _ValueFn.apply(x, self, *_flat_param_list(self))
+        except Exception as e:
+            if self.logger is not None:
+                self.logger.print(f"Forward pass failed: {str(e)}")
+            raise
+
+    def residual(self, X: torch.Tensor, D=0.01, v_x=1.0, v_y=1.0):
+        """(u, residual) at X (B,3) with the derivative channels carried through the HIP kernels —
+        what ``nn.pde.diffusion_operator`` dispatches to for this model."""
+        if X.dim() != 2 or X.shape[1] != 3:
+            raise ValueError(f"Expected collocation points of shape (B, 3), got {tuple(X.shape)}")
+        self._engine_for(X.device)
+        return _ResidualFn.apply(X, self, (float(D), float(v_x), float(v_y)), *_flat_param_list(self))
+
+    # ------------------------------------------------------------------ checkpoint (same keys as :116-128)
+    def save_state(self, path=None):
+        sync = getattr(self, "_sync_fused_to_torch", None)
+        if sync is not None:
+            sync()
+        state = {
+            "args": self.args,
+            "classic_network": self.classic_network,
+            "quantum_params": self.quantum_layer.state_dict(),
+            "preprocessor": self.preprocessor.state_dict(),
+            "quantum_layer": self.quantum_layer.state_dict(),
+            "postprocessor": self.postprocessor.state_dict(),
+            "optimizer": self.optimizer.state_dict(),
+            "scheduler": self.scheduler.state_dict(),
+            "loss_history": self.loss_history,
+            "log_path": self.log_path,
+        }
+        model_path = os.path.join(self.log_path, "model.pth") if path is None else path
+        with open(model_path, "wb") as f:
+            torch.save(state, f)
+        if self.logger is not None:
+            self.logger.print(f"Model state saved to {model_path}")
+
+    @classmethod
+    def load_state(cls, file_path, map_location=None):
+        if map_location is None:
+            map_location = torch.device("cpu")
+        with open(file_path, "rb") as f:     # tensors, lists, numbers, strings, torch.device only
+            return torch.load(f, map_location=map_location, weights_only=True)
+
+    def draw_quantum_circuit(self, x):
+        """The reference renders the QNode to circuit.pdf with matplotlib (:144-158); here the gate
+        program is written as text to the log (plots are out of scope)."""
+        if self.draw_quantum_circuit_flag and self.logger is not None:
+            try:
+                self.logger.print("The circuit used in the study:")
+                self.logger.print(self.quantum_layer.describe())
+            except Exception as e:
+                self.logger.print(f"Failed to draw quantum circuit: {str(e)}")
