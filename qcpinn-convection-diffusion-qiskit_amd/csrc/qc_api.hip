@@ -29,8 +29,12 @@ static QcPde to_pde(const qc_pde* p) {
 
 // Which kernel family serves n qubits: registers (one lane per statevector) up to 5,
 // lanes-as-amplitudes above.
-static inline bool use_reg(int n) { return n >= 2 && n <= 5; }
-static inline bool use_wave(int n) { return n >= 1 && n <= 10; }
+static inline bool force_wave() {
+  static const bool f = [] { const char* e = getenv("QC_FORCE_WAVE"); return e && e[0] == '1'; }();
+  return f;   // test hook: route n <= 5 through the wave family too (cross-checks the two families)
+}
+static inline bool use_reg(int n) { return n >= 2 && n <= 5 && !force_wave(); }
+static inline bool use_wave(int n) { return n >= 1 && n <= 8; }
 
 extern "C" {
 

@@ -43,8 +43,7 @@ def flat_grad(model):
     return torch.cat([(torch.zeros_like(p) if p.grad is None else p.grad).reshape(-1) for p in model.parameters()])
 
 
-OPERATOR_CASES = [("cascade_n4", {}), ("cross_mesh_n4", {"q_ansatz": "cross_mesh"})]
-_LATER = [
+OPERATOR_CASES = [("cascade_n4", {}), ("cross_mesh_n4", {"q_ansatz": "cross_mesh"}),
                   ("layered_n8", {"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"})]
 
 
@@ -76,8 +75,8 @@ def test_diffusion_operator_matches_reference_pde(tag, over, gpu_device, tmp_pat
     assert np.abs(g - z["grad"]).max() < 2e-4 * gs
 
 
-TRAIN_CASES = [("cascade_n4_b64", {"epochs": 20}), ("cascade_n4_b128", {"epochs": 8})]
-_LATER_T = [("layered_n8_b32", {"epochs": 5, "num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"})]
+TRAIN_CASES = [("cascade_n4_b64", {"epochs": 20}), ("cascade_n4_b128", {"epochs": 8}),
+               ("layered_n8_b32", {"epochs": 5, "num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"})]
 
 
 @pytest.mark.parametrize("tag,over", TRAIN_CASES)
