@@ -85,6 +85,7 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   }
   p->n_qubits = n_qubits; p->n_gates = n_gates; p->n_params = n_params; p->n_u4 = n_u4;
   p->h_gates = h; p->d_gates = nullptr;
+  p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p) : -1;
   hipError_t e = hipMalloc((void**)&p->d_gates, sizeof(QcGate) * n_gates);
   if (e == hipSuccess) e = hipMemcpy(p->d_gates, h, sizeof(QcGate) * n_gates, hipMemcpyHostToDevice);
   if (e != hipSuccess) {

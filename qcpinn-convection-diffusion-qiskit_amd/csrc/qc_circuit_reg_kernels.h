@@ -1,0 +1,499 @@
+// Variational-circuit kernels, "reg" family: 2 <= n <= 5 qubits, one lane = one statevector
+// held entirely in VGPRs (qc_gates.h).  Replaces the PennyLane default.qubit simulation behind
+// DVQuantumLayer.forward (reference nn/DVQuantumLayer.py:151-154,176-214) and the torch
+// double-backward through it that nn/pde.py:59-70 + loss.backward() trigger.
+//
+// Four kernels per qubit count:
+//   value_fwd : angles[n][B]            -> <Z_w>[n][B]                       (1 channel)
+//   value_bwd : angles, cot[n][B]       -> d_angles[n][B], d_theta partial rows
+//   jets_fwd  : angle jets[6][n][B]     -> <Z_w> jets[6][n][B]               (6 channels)
+//   jets_bwd  : angle jets, cot jets    -> d(angle jets)[6][n][B], d_theta partial rows
+// Channels: 0 value, 1 d/dt, 2 d/dx, 3 d/dy, 4 d2/dx2, 5 d2/dy2 (forward-mode derivatives of the
+// circuit output w.r.t. the collocation coordinates; the gates are linear so every channel runs
+// the same gate program on its own initial vector).  In the jet kernels a block is 6 waves x 64
+// points: wave c carries channel c of the block's 64 points, channels meet through LDS only
+// where the bilinear <Z> forms and their cotangents couple them.
+//
+// Batch-minor ([feature][B]) layouts make every global access 64 consecutive floats per wave.
+#pragma once
+#include "qc_gates.h"
+#include "qc_internal.h"
+
+#include <utility>
+
+namespace {
+
+// ------------------------------------------------------------------ program policies
+// DynProg<N>: the gate program is run-time data (scalar switch per gate, any ansatz).
+template <int NQ>
+struct DynProg {
+  static constexpr int N = NQ;
+  __device__ static __forceinline__ void fwd(SV<NQ> (&v)[1], const QcGate* __restrict__ prog,
+                                             const QcTrig* __restrict__ trig, const float* __restrict__ umat,
+                                             int n_gates) {
+    for (int g = 0; g < n_gates; ++g) {
+      const QcGate gt = prog[g];
+      const QcTrig tr = trig[g];
+      qc_apply_gate<NQ, 1, false>(v, gt, tr.c, tr.s, umat);
+    }
+  }
+  // Reverse sweep for one (chi, lam) pair: accumulates Im<lam|G|chi> per parameter slot into
+  // acc_wave[slot] (LDS, one row per wave), then un-applies the gate on both.
+  __device__ static __forceinline__ void bwd(SV<NQ> (&cl)[2], const QcGate* __restrict__ prog,
+                                             const QcTrig* __restrict__ trig, const float* __restrict__ umat,
+                                             int n_gates, float* __restrict__ acc_wave, int lane) {
+    for (int g = n_gates - 1; g >= 0; --g) {
+      const QcGate gt = prog[g];
+      const QcTrig tr = trig[g];
+      if (gt.op != QC_U4 && gt.slot >= 0) {
+        const float gr = qc_wave_sum_to_lane63(qc_gate_grad<NQ>(cl[1], cl[0], gt));
+        if (lane == 63) acc_wave[gt.slot] += gr;
+      }
+      qc_apply_gate<NQ, 2, true>(cl, gt, tr.c, tr.s, umat);
+    }
+  }
+};
+
+// StatProg<SP>: the gate list is a compile-time constant (SP::g[], generated from circuits.py by
+// gen_static.py), so the whole circuit is straight-line code: no dispatch, no register shuffling
+// at control-flow merges, trig table entries at constant offsets (scalar loads).
+struct SGate {
+  int op, ba, bb, slot;
+};
+
+template <int NQ, int K, bool ADJ, int OP, int BA, int BB, int SLOT>
+__device__ __forceinline__ void qc_static_gate(SV<NQ> (&v)[K], const float c, const float s_in,
+                                               const float* __restrict__ umat) {
+  const float s = ADJ ? -s_in : s_in;
+#pragma unroll
+  for (int q = 0; q < K; ++q) {
+    if constexpr (OP == QC_RX) g_rx<NQ, BA>(v[q], c, s);
+    else if constexpr (OP == QC_RY) g_ry<NQ, BA>(v[q], c, s);
+    else if constexpr (OP == QC_RZ) g_rz<NQ, BA>(v[q], c, s);
+    else if constexpr (OP == QC_H) g_h<NQ, BA>(v[q]);
+    else if constexpr (OP == QC_CNOT) g_cnot<NQ, BA, BB>(v[q]);
+    else if constexpr (OP == QC_CRX) g_crx<NQ, BA, BB>(v[q], c, s);
+    else if constexpr (OP == QC_CRZ) g_crz<NQ, BA, BB>(v[q], c, s);
+    else if constexpr (OP == QC_U4) g_u4<NQ, BA, BB>(v[q], umat + (SLOT * 2 + (ADJ ? 1 : 0)) * 32);
+  }
+}
+
+template <int NQ, int OP, int BA, int BB>
+__device__ __forceinline__ float qc_static_grad(const SV<NQ>& lam, const SV<NQ>& chi) {
+  if constexpr (OP == QC_RX) return ip_x<NQ, BA>(lam, chi);
+  else if constexpr (OP == QC_RY) return ip_y<NQ, BA>(lam, chi);
+  else if constexpr (OP == QC_RZ) return ip_z<NQ, BA>(lam, chi);
+  else if constexpr (OP == QC_CRX) return ip_cx<NQ, BA, BB>(lam, chi);
+  else if constexpr (OP == QC_CRZ) return ip_cz<NQ, BA, BB>(lam, chi);
+  else return 0.f;
+}
+
+template <class SP>
+struct StatProg {
+  static constexpr int N = SP::N;
+  template <int I>
+  __device__ static __forceinline__ void fwd_one(SV<N> (&v)[1], const QcTrig* __restrict__ trig,
+                                                 const float* __restrict__ umat) {
+    constexpr SGate g = SP::g[I];
+    float c = 1.f, s = 0.f;
+    if constexpr (g.op != QC_U4 && g.slot >= 0) {
+      const QcTrig tr = trig[I];
+      c = tr.c;
+      s = tr.s;
+    }
+    qc_static_gate<N, 1, false, g.op, g.ba, g.bb, g.slot>(v, c, s, umat);
+  }
+  template <int... Is>
+  __device__ static __forceinline__ void fwd_all(SV<N> (&v)[1], const QcTrig* __restrict__ trig,
+                                                 const float* __restrict__ umat, std::integer_sequence<int, Is...>) {
+    (fwd_one<Is>(v, trig, umat), ...);
+  }
+  __device__ static __forceinline__ void fwd(SV<N> (&v)[1], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
+                                             const float* __restrict__ umat, int) {
+    fwd_all(v, trig, umat, std::make_integer_sequence<int, SP::G>{});
+  }
+  template <int J>
+  __device__ static __forceinline__ void bwd_one(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
+                                                 const float* __restrict__ umat, float* __restrict__ acc_wave,
+                                                 int lane) {
+    constexpr int I = SP::G - 1 - J;
+    constexpr SGate g = SP::g[I];
+    float c = 1.f, s = 0.f;
+    if constexpr (g.op != QC_U4 && g.slot >= 0) {
+      const QcTrig tr = trig[I];
+      c = tr.c;
+      s = tr.s;
+      const float gr = qc_wave_sum_to_lane63(qc_static_grad<N, g.op, g.ba, g.bb>(cl[1], cl[0]));
+      if (lane == 63) acc_wave[g.slot] += gr;
+    }
+    qc_static_gate<N, 2, true, g.op, g.ba, g.bb, g.slot>(cl, c, s, umat);
+  }
+  template <int... Js>
+  __device__ static __forceinline__ void bwd_all(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
+                                                 const float* __restrict__ umat, float* __restrict__ acc_wave,
+                                                 int lane, std::integer_sequence<int, Js...>) {
+    (bwd_one<Js>(cl, trig, umat, acc_wave, lane), ...);
+  }
+  __device__ static __forceinline__ void bwd(SV<N> (&cl)[2], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
+                                             const float* __restrict__ umat, int, float* __restrict__ acc_wave,
+                                             int lane) {
+    bwd_all(cl, trig, umat, acc_wave, lane, std::make_integer_sequence<int, SP::G>{});
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void load_sincos(float (&ca)[N], float (&sa)[N], const float* __restrict__ a,
+                                            int64_t B, int64_t p) {
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    const float h = 0.5f * a[(int64_t)w * B + p];
+    sincosf(h, &sa[w], &ca[w]);
+  }
+}
+
+// ================================================================== value channel only
+template <class PG>
+__global__ void __launch_bounds__(256) k_value_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                   const float* __restrict__ umat, int n_gates,
+                                                   const float* __restrict__ angles, float* __restrict__ expval,
+                                                   int64_t B) {
+  constexpr int N = PG::N;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t pc = p < B ? p : B - 1;
+  float ca[N], sa[N], zero[N];
+#pragma unroll
+  for (int w = 0; w < N; ++w) zero[w] = 0.f;
+  load_sincos<N>(ca, sa, angles, B, pc);
+  float P0[1 << N], P1[1 << N], P2[1 << N];
+  qc_embed_series<N, 0>(P0, P1, P2, ca, sa, zero, zero);
+  SV<N> v[1];
+  qc_phase_load<N>(v[0], P0);
+  PG::fwd(v, prog, trig, umat, n_gates);
+  float t[1 << N], q[N];
+#pragma unroll
+  for (int k = 0; k < (1 << N); ++k) t[k] = v[0].re[k] * v[0].re[k] + v[0].im[k] * v[0].im[k];
+  qc_signed_sums<N>(q, t);
+  if (p < B) {
+#pragma unroll
+    for (int w = 0; w < N; ++w) expval[(int64_t)w * B + p] = q[w];
+  }
+}
+
+template <class PG>
+__global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                   const float* __restrict__ umat, int n_gates, int n_params,
+                                                   const float* __restrict__ angles, const float* __restrict__ cot,
+                                                   float* __restrict__ d_angles, float* __restrict__ part,
+                                                   int64_t part_stride, int64_t row0, int64_t B) {
+  constexpr int N = PG::N;
+  extern __shared__ float smem[];  // [4 waves][n_params]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 4 * n_params; i += 256) smem[i] = 0.f;
+  __syncthreads();
+
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+  float ca[N], sa[N], zero[N];
+#pragma unroll
+  for (int w = 0; w < N; ++w) zero[w] = 0.f;
+  load_sincos<N>(ca, sa, angles, B, pc);
+  float P0[1 << N], P1[1 << N], P2[1 << N];
+  qc_embed_series<N, 0>(P0, P1, P2, ca, sa, zero, zero);
+  SV<N> cl[2];  // [0] = chi, [1] = lambda
+  {
+    SV<N> v[1];
+    qc_phase_load<N>(v[0], P0);
+    PG::fwd(v, prog, trig, umat, n_gates);
+    cl[0] = v[0];
+  }
+  float qb[N];
+#pragma unroll
+  for (int w = 0; w < N; ++w) qb[w] = live ? cot[(int64_t)w * B + pc] : 0.f;
+#pragma unroll
+  for (int k = 0; k < (1 << N); ++k) {
+    float d = 0.f;
+#pragma unroll
+    for (int w = 0; w < N; ++w) d += ((k >> (N - 1 - w)) & 1) ? -qb[w] : qb[w];
+    cl[1].re[k] = d * cl[0].re[k];
+    cl[1].im[k] = d * cl[0].im[k];
+  }
+  PG::bwd(cl, prog, trig, umat, n_gates, smem + wave * n_params, lane);
+  float T[N];
+  qc_embed_ip<N>(T, cl[1], P0);
+  if (live) {
+#pragma unroll
+    for (int w = 0; w < N; ++w) d_angles[(int64_t)w * B + p] = T[w];
+  }
+  __syncthreads();
+  // one partial row per wave = per 64-point tile (same tiling as the MLP kernels)
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  if (tile * 64 < B)
+    for (int i = lane; i < n_params; i += 64) part[(row0 + tile) * part_stride + i] = smem[wave * n_params + i];
+}
+
+// ================================================================== six derivative channels
+// Builds the initial vector of channel `ch` for this lane's point.  P0/P1/P2 are left holding
+// the embedding series of the channel's direction (needed again by the backward kernel).
+template <int N>
+__device__ __forceinline__ void build_channel(SV<N>& v, float (&P0)[1 << N], float (&P1)[1 << N],
+                                              float (&P2)[1 << N], int ch, const float* __restrict__ ajets,
+                                              int64_t B, int64_t pc) {
+  float ca[N], sa[N], da[N], dda[N];
+  load_sincos<N>(ca, sa, ajets, B, pc);
+  const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);  // channel holding the first derivative
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    da[w] = ch >= 1 ? ajets[((int64_t)dirch * N + w) * B + pc] : 0.f;
+    dda[w] = ch >= 4 ? ajets[((int64_t)ch * N + w) * B + pc] : 0.f;
+  }
+  if (ch == 0) {
+    qc_embed_series<N, 0>(P0, P1, P2, ca, sa, da, dda);
+    qc_phase_load<N>(v, P0);
+  } else if (ch <= 3) {
+    qc_embed_series<N, 1>(P0, P1, P2, ca, sa, da, dda);
+    qc_phase_load<N>(v, P1);
+  } else {
+    qc_embed_series<N, 2>(P0, P1, P2, ca, sa, da, dda);
+    qc_phase_load<N>(v, P2);
+  }
+}
+
+template <class PG>
+__global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                  const float* __restrict__ umat, int n_gates,
+                                                  const float* __restrict__ ajets, float* __restrict__ qjets,
+                                                  int64_t B) {
+  constexpr int N = PG::N;
+  constexpr int A2 = 2 << N;                 // floats per statevector
+  __shared__ float s_chi0[A2 * 64];          // [amp*2+{re,im}][lane]
+  __shared__ float s_sq[2 * N * 64];         // 2<chi_k|Z_w|chi_k> for k = x, y
+  const int lane = threadIdx.x & 63;
+  const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index = channel (scalar)
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t pc = p < B ? p : B - 1;
+
+  SV<N> v[1];
+  float P0[1 << N], P1[1 << N], P2[1 << N];
+  build_channel<N>(v[0], P0, P1, P2, ch, ajets, B, pc);
+  PG::fwd(v, prog, trig, umat, n_gates);
+
+  float t[1 << N], q[N];
+  if (ch == 0) {
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      s_chi0[(2 * k) * 64 + lane] = v[0].re[k];
+      s_chi0[(2 * k + 1) * 64 + lane] = v[0].im[k];
+      t[k] = v[0].re[k] * v[0].re[k] + v[0].im[k] * v[0].im[k];
+    }
+    qc_signed_sums<N>(q, t);
+  } else if (ch == 2 || ch == 3) {
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) t[k] = 2.f * (v[0].re[k] * v[0].re[k] + v[0].im[k] * v[0].im[k]);
+    qc_signed_sums<N>(q, t);
+#pragma unroll
+    for (int w = 0; w < N; ++w) s_sq[((ch - 2) * N + w) * 64 + lane] = q[w];
+  }
+  __syncthreads();
+  if (ch != 0) {
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      const float r0 = s_chi0[(2 * k) * 64 + lane], i0 = s_chi0[(2 * k + 1) * 64 + lane];
+      t[k] = 2.f * (r0 * v[0].re[k] + i0 * v[0].im[k]);
+    }
+    qc_signed_sums<N>(q, t);
+    if (ch >= 4) {
+#pragma unroll
+      for (int w = 0; w < N; ++w) q[w] += s_sq[((ch - 4) * N + w) * 64 + lane];
+    }
+  }
+  if (p < B) {
+#pragma unroll
+    for (int w = 0; w < N; ++w) qjets[((int64_t)ch * N + w) * B + p] = q[w];
+  }
+}
+
+template <class PG>
+__global__ void __launch_bounds__(384) k_jets_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                  const float* __restrict__ umat, int n_gates, int n_params,
+                                                  const float* __restrict__ ajets, const float* __restrict__ qbar,
+                                                  float* __restrict__ abar, float* __restrict__ part,
+                                                  int64_t part_stride, int64_t row0, int64_t B) {
+  constexpr int N = PG::N;
+  constexpr int A2 = 2 << N;
+  extern __shared__ float smem[];
+  float* s_chi = smem;                       // [6][A2][64]; later reused as [6 waves][3][N][64]
+  float* s_acc = smem + 6 * A2 * 64;         // [6 waves][n_params]
+  const int lane = threadIdx.x & 63;
+  const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 6 * n_params; i += 384) s_acc[i] = 0.f;
+
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+
+  SV<N> cl[2];
+  float P0[1 << N], P1[1 << N], P2[1 << N];
+  {
+    SV<N> v[1];
+    build_channel<N>(v[0], P0, P1, P2, ch, ajets, B, pc);
+    PG::fwd(v, prog, trig, umat, n_gates);
+    cl[0] = v[0];
+  }
+  float* mine = s_chi + ch * A2 * 64;
+#pragma unroll
+  for (int k = 0; k < (1 << N); ++k) {
+    mine[(2 * k) * 64 + lane] = cl[0].re[k];
+    mine[(2 * k + 1) * 64 + lane] = cl[0].im[k];
+  }
+  __syncthreads();
+
+  // ---- cotangent of this channel's final state (bilinear <Z> forms)
+  auto dvec = [&](int c, float (&d)[1 << N]) {
+    float qb[N];
+#pragma unroll
+    for (int w = 0; w < N; ++w) qb[w] = live ? qbar[((int64_t)c * N + w) * B + pc] : 0.f;
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < N; ++w) s += ((k >> (N - 1 - w)) & 1) ? -qb[w] : qb[w];
+      d[k] = s;
+    }
+  };
+  float d[1 << N];
+  if (ch == 0) {
+    dvec(0, d);
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      cl[1].re[k] = d[k] * cl[0].re[k];
+      cl[1].im[k] = d[k] * cl[0].im[k];
+    }
+    for (int c = 1; c < QC_NCH; ++c) {
+      dvec(c, d);
+      const float* other = s_chi + c * A2 * 64;
+#pragma unroll
+      for (int k = 0; k < (1 << N); ++k) {
+        cl[1].re[k] = fmaf(d[k], other[(2 * k) * 64 + lane], cl[1].re[k]);
+        cl[1].im[k] = fmaf(d[k], other[(2 * k + 1) * 64 + lane], cl[1].im[k]);
+      }
+    }
+  } else {
+    dvec(ch, d);
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      cl[1].re[k] = d[k] * s_chi[(2 * k) * 64 + lane];
+      cl[1].im[k] = d[k] * s_chi[(2 * k + 1) * 64 + lane];
+    }
+    if (ch == 2 || ch == 3) {
+      dvec(ch + 2, d);
+#pragma unroll
+      for (int k = 0; k < (1 << N); ++k) {
+        cl[1].re[k] = fmaf(2.f * d[k], cl[0].re[k], cl[1].re[k]);
+        cl[1].im[k] = fmaf(2.f * d[k], cl[0].im[k], cl[1].im[k]);
+      }
+    }
+  }
+  __syncthreads();  // everyone is done reading s_chi
+
+  PG::bwd(cl, prog, trig, umat, n_gates, s_acc + ch * n_params, lane);
+
+  // ---- cotangents of the angle jets: Im<Lambda| X_w |phi> against the embedding series
+  float* buf = s_chi + ch * 3 * N * 64;  // [3][N][64] per wave
+  float T[N];
+  if (ch == 0) {
+    qc_embed_ip<N>(T, cl[1], P0);
+#pragma unroll
+    for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
+  } else if (ch <= 3) {
+    qc_embed_ip<N>(T, cl[1], P1);
+#pragma unroll
+    for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
+    qc_embed_ip<N>(T, cl[1], P0);
+#pragma unroll
+    for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = T[w];
+  } else {
+    qc_embed_ip<N>(T, cl[1], P2);
+#pragma unroll
+    for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
+    qc_embed_ip<N>(T, cl[1], P1);
+#pragma unroll
+    for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = 2.f * T[w];
+    qc_embed_ip<N>(T, cl[1], P0);
+#pragma unroll
+    for (int w = 0; w < N; ++w) buf[(2 * N + w) * 64 + lane] = T[w];
+  }
+  __syncthreads();
+  auto at = [&](int wv, int slot, int w) { return s_chi[((wv * 3 + slot) * N + w) * 64 + lane]; };
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    float r;
+    if (ch == 0)
+      r = ((at(0, 0, w) + at(1, 0, w)) + (at(2, 0, w) + at(3, 0, w))) + (at(4, 0, w) + at(5, 0, w));
+    else if (ch == 1)
+      r = at(1, 1, w);
+    else if (ch <= 3)
+      r = at(ch, 1, w) + at(ch + 2, 1, w);
+    else
+      r = at(ch, 2, w);
+    if (live) abar[((int64_t)ch * N + w) * B + p] = r;
+  }
+  for (int i = threadIdx.x; i < n_params; i += 384) {
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < 6; ++wv) s += s_acc[wv * n_params + i];
+    part[(row0 + blockIdx.x) * part_stride + i] = s;
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ launch helpers (per policy)
+struct QcRegLaunchers {
+  int (*value_fwd)(const qc_program*, const QcTrig*, const float*, const float*, float*, int64_t, hipStream_t);
+  int (*value_bwd)(const qc_program*, const QcTrig*, const float*, const float*, const float*, float*, float*,
+                   int64_t, int64_t, int64_t, hipStream_t);
+  int (*jets_fwd)(const qc_program*, const QcTrig*, const float*, const float*, float*, int64_t, hipStream_t);
+  int (*jets_bwd)(const qc_program*, const QcTrig*, const float*, const float*, const float*, float*, float*,
+                  int64_t, int64_t, int64_t, hipStream_t);
+};
+
+template <class PG>
+struct RegLaunch {
+  static int value_fwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* angles,
+                       float* expval, int64_t B, hipStream_t st) {
+    hipLaunchKernelGGL(k_value_fwd<PG>, dim3(qc_ceil_div(B, 256)), dim3(256), 0, st, pg->d_gates, trig, umat,
+                       pg->n_gates, angles, expval, B);
+    return QC_OK;
+  }
+  static int value_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* angles,
+                       const float* cot, float* d_angles, float* part, int64_t part_stride, int64_t row0,
+                       int64_t B, hipStream_t st) {
+    const size_t sh = (size_t)4 * pg->n_params * sizeof(float);
+    hipLaunchKernelGGL(k_value_bwd<PG>, dim3(qc_ceil_div(B, 256)), dim3(256), sh, st, pg->d_gates, trig, umat,
+                       pg->n_gates, pg->n_params, angles, cot, d_angles, part, part_stride, row0, B);
+    return QC_OK;
+  }
+  static int jets_fwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
+                      float* qjets, int64_t B, hipStream_t st) {
+    hipLaunchKernelGGL(k_jets_fwd<PG>, dim3(qc_ceil_div(B, 64)), dim3(384), 0, st, pg->d_gates, trig, umat,
+                       pg->n_gates, ajets, qjets, B);
+    return QC_OK;
+  }
+  static int jets_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
+                      const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
+                      hipStream_t st) {
+    const size_t sh = ((size_t)6 * (2u << PG::N) * 64 + (size_t)6 * pg->n_params) * sizeof(float);
+    if (sh > 160 * 1024) return QC_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jets_bwd<PG>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_jets_bwd<PG>, dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
+                       pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B);
+    return QC_OK;
+  }
+  static constexpr QcRegLaunchers table() { return {&value_fwd, &value_bwd, &jets_fwd, &jets_bwd}; }
+};

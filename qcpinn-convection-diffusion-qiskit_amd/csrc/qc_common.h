@@ -33,6 +33,7 @@ struct qc_program {
   int n_gates;
   int n_params;
   int n_u4;
+  int static_id;    // index into the compile-time specialised programs, or -1
   QcGate* d_gates;  // device
   QcGate* h_gates;  // host copy
 };

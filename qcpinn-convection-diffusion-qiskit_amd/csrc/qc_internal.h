@@ -54,6 +54,7 @@ struct QcOptHyper {  // == qc_opt_hyper of the public header
 };
 
 // ---- launchers, one group per .hip file
+int qc_reg_match_static(const qc_program* pg);
 int qc_reg_value_fwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, float* expval,
                      int64_t B, hipStream_t);
 int qc_reg_value_bwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, const float* cot,
