@@ -83,7 +83,8 @@ typedef struct qc_pde {
 
 /* mode 0: qjets -> u [B], residual [B] (nn/pde.py:71);
  * mode 1: cotangents (ubar, rbar) [B] -> qbar jets + weight-gradient partial rows;
- * mode 2: forward + analytic targets (data/diffusion_dataset.py:20-38) + squared error + reverse. */
+ * mode 2: forward + analytic targets (data/diffusion_dataset.py:20-38) + squared error + reverse;
+ *         out_u_dev / out_res_dev are then B-float scratch buffers (per-point cotangents). */
 int qc_post(int mode, const float* X_dev, const float* params_dev, int H, int n, int n_theta,
             const qc_pde* pde, const float* qjets_dev, float* out_u_dev, float* out_res_dev,
             const float* in_ubar_dev, const float* in_rbar_dev, float* qbar_dev, float* part_dev,

@@ -203,6 +203,7 @@ int qc_post(int mode, const float* X, const float* prm, int H, int n, int n_thet
   const QcLayout L = make_layout(H, n, n_theta);
   if (mode < 0 || mode > 2 || !X || !prm || !pde || !qjets) return QC_ERR_ARG;
   if (mode >= 1 && (!qbar || !part || row0 < 0 || part_stride < L.NP + (mode == 2 ? 3 : 0))) return QC_ERR_ARG;
+  if (mode == 2 && (!out_u || (nch == 6 && !out_res))) return QC_ERR_ARG;  // per-point cotangent scratch
   rc = qc_mlp_post(mode, X, prm, L, to_pde(pde), qjets, out_u, out_res, in_ubar, in_rbar, qbar, part, part_stride,
                    row0, B, nch, (hipStream_t)stream);
   return rc ? rc : after_launch();
@@ -246,8 +247,10 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
         return QC_ERR_ARG;
       if ((rc = qc_pre_forward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->ajets_res_dev, d->B_res, 6, st))) return rc;
       if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, st))) return rc;
-      if ((rc = qc_post(2, d->X_res_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_res_dev, nullptr, nullptr,
-                        nullptr, nullptr, d->qbar_res_dev, d->part_dev, d->part_stride, 0, d->B_res, 6, st))) return rc;
+      // abar_res is written only by the adjoint sweep below: its head serves as cotangent scratch here
+      if ((rc = qc_post(2, d->X_res_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_res_dev,
+                        d->abar_res_dev, d->abar_res_dev + d->B_res, nullptr, nullptr, d->qbar_res_dev, d->part_dev,
+                        d->part_stride, 0, d->B_res, 6, st))) return rc;
       if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
                                  d->part_dev + L.oTh, d->part_stride, 0, d->B_res, st))) return rc;
       if ((rc = qc_pre_backward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->abar_res_dev, d->part_dev,
@@ -258,8 +261,9 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
         return QC_ERR_ARG;
       if ((rc = qc_pre_forward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->ajets_val_dev, d->B_val, 1, st))) return rc;
       if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qjets_val_dev, d->B_val, st))) return rc;
-      if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev, nullptr, nullptr,
-                        nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride, rows_res, d->B_val, 1, st))) return rc;
+      if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev,
+                        d->abar_val_dev, nullptr, nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride,
+                        rows_res, d->B_val, 1, st))) return rc;
       if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev,
                                    d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, st))) return rc;
       if ((rc = qc_pre_backward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->abar_val_dev, d->part_dev,

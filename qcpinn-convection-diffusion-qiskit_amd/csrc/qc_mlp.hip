@@ -21,7 +21,12 @@
 
 namespace {
 
-__device__ __forceinline__ float qc_tanh(float x) { return tanhf(x); }
+// tanh(x) = 1 - 2/(exp(2x)+1) on the hardware exp/rcp units (abs. error ~1e-7; saturates cleanly
+// to +-1 for |x| large, where exp overflows to inf or underflows to 0).
+__device__ __forceinline__ float qc_tanh(float x) {
+  const float e = __expf(2.f * x);
+  return 1.f - 2.f * __frcp_rn(e + 1.f);
+}
 
 // analytic solution and forcing term, data/diffusion_dataset.py:20-38
 __device__ __forceinline__ float analytic_u(float t, float x, float y) {
@@ -38,11 +43,18 @@ __device__ __forceinline__ float analytic_r(float t, float x, float y, float D, 
 }
 
 // ================================================================== pre network, forward jets
-// lane = collocation point; loop over hidden units with wave-uniform (scalar) weights.
+// Block = 4 waves on ONE 64-point tile: lane = collocation point, wave w takes a quarter of the
+// hidden units (wave-uniform weights -> scalar loads); the four partial angle jets meet in LDS.
+// Four waves per tile (instead of one) keep >= 4 waves per SIMD in flight at B = 65 536.
+constexpr int QC_MS = 4;
+
 template <int N, int NCH>
 __global__ void __launch_bounds__(256) k_pre_fwd(const float* __restrict__ X, const float* __restrict__ prm,
                                                  QcLayout L, float* __restrict__ ajets, int64_t B) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float s_part[QC_MS][NCH * N][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
   const int64_t pc = p < B ? p : B - 1;
   const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
   float acc[NCH][N];
@@ -53,7 +65,9 @@ __global__ void __launch_bounds__(256) k_pre_fwd(const float* __restrict__ X, co
   const float* W1 = prm + L.oW1;
   const float* b1 = prm + L.ob1;
   const float* W2 = prm + L.oW2;
-  for (int m = 0; m < L.H; ++m) {
+  const int hq = (L.H + QC_MS - 1) / QC_MS;
+  const int m0 = wave * hq, m1 = (m0 + hq) < L.H ? (m0 + hq) : L.H;
+  for (int m = m0; m < m1; ++m) {
     const float w0 = W1[3 * m], w1 = W1[3 * m + 1], w2 = W1[3 * m + 2];
     const float h = fmaf(w0, t, fmaf(w1, x, fmaf(w2, y, b1[m])));
     const float z = qc_tanh(h);
@@ -74,26 +88,31 @@ __global__ void __launch_bounds__(256) k_pre_fwd(const float* __restrict__ X, co
       for (int c = 0; c < NCH; ++c) acc[c][i] = fmaf(wi, zc[c], acc[c][i]);
     }
   }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) s_part[wave][c * N + i][lane] = acc[c][i];
+  __syncthreads();
   if (p < B) {
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      ajets[(int64_t)i * B + p] = acc[0][i] + prm[L.ob2 + i];
-#pragma unroll
-      for (int c = 1; c < NCH; ++c) ajets[((int64_t)c * N + i) * B + p] = acc[c][i];
+    for (int f = wave; f < NCH * N; f += QC_MS) {
+      float v = (s_part[0][f][lane] + s_part[1][f][lane]) + (s_part[2][f][lane] + s_part[3][f][lane]);
+      if (f < N) v += prm[L.ob2 + f];
+      ajets[(int64_t)f * B + p] = v;
     }
   }
 }
 
 // ================================================================== pre network, reverse pass
 // lane = hidden unit (each lane owns one row of W1 / column of W2, so weight gradients need no
-// cross-lane reduction); the block walks its tile of 64 points, whose coordinates and angle-jet
-// cotangents are staged in LDS and read as broadcasts.
+// cross-lane reduction).  The block's 64-point tile is staged in LDS and split over PS groups of HB
+// threads (16 points each, read as LDS broadcasts); the groups' accumulators meet in LDS.
 template <int N, int NCH>
 __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
                           const float* __restrict__ abar, float* __restrict__ part, int64_t part_stride,
-                          int64_t row0, int64_t B) {
+                          int64_t row0, int64_t B, int HB, int PS) {
   __shared__ float sX[3][64];
   __shared__ float sA[NCH * N][64];
+  extern __shared__ float s_acc[];  // [PS][4 + N][HB]
   const int64_t base = (int64_t)blockIdx.x * 64;
   const int cnt = (int)((B - base) < 64 ? (B - base) : 64);
   for (int i = threadIdx.x; i < 64 * 3; i += blockDim.x) {
@@ -106,18 +125,19 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
   }
   __syncthreads();
 
-  const int m = threadIdx.x;
-  float* row = part + (row0 + blockIdx.x) * part_stride;
+  const int grp = threadIdx.x / HB, m = threadIdx.x % HB;
+  const int per = 64 / PS;
+  const int p0 = grp * per, p1 = (p0 + per) < cnt ? (p0 + per) : cnt;
+  float gW1[3] = {0.f, 0.f, 0.f}, gb1 = 0.f, gW2[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) gW2[i] = 0.f;
   if (m < L.H) {
     const float w0 = prm[L.oW1 + 3 * m], w1 = prm[L.oW1 + 3 * m + 1], w2 = prm[L.oW1 + 3 * m + 2];
     const float bb = prm[L.ob1 + m];
     float w2c[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) w2c[i] = prm[L.oW2 + i * L.H + m];
-    float gW1[3] = {0.f, 0.f, 0.f}, gb1 = 0.f, gW2[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) gW2[i] = 0.f;
-    for (int pp = 0; pp < cnt; ++pp) {
+    for (int pp = p0; pp < p1; ++pp) {
       const float t = sX[0][pp], x = sX[1][pp], y = sX[2][pp];
       const float h = fmaf(w0, t, fmaf(w1, x, fmaf(w2, y, bb)));
       const float z = qc_tanh(h);
@@ -125,10 +145,10 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
       float zb[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        float s = 0.f;
+        float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) s = fmaf(w2c[i], sA[c * N + i][pp], s);
-        zb[c] = s;
+        for (int i = 0; i < N; ++i) sum = fmaf(w2c[i], sA[c * N + i][pp], sum);
+        zb[c] = sum;
       }
       if constexpr (NCH == 6) {
         const float d2 = -2.f * z * d1;
@@ -136,10 +156,10 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
         const float zc[6] = {z, d1 * w0, d1 * w1, d1 * w2, d2 * w1 * w1, d2 * w2 * w2};
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-          float s = gW2[i];
+          float sum = gW2[i];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) s = fmaf(sA[c * N + i][pp], zc[c], s);
-          gW2[i] = s;
+          for (int c = 0; c < 6; ++c) sum = fmaf(sA[c * N + i][pp], zc[c], sum);
+          gW2[i] = sum;
         }
         const float hb = zb[0] * d1 + (zb[1] * w0 + zb[2] * w1 + zb[3] * w2) * d2 +
                          (zb[4] * w1 * w1 + zb[5] * w2 * w2) * d3;
@@ -157,34 +177,94 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
         gb1 += hb;
       }
     }
-    row[L.oW1 + 3 * m] = gW1[0];
-    row[L.oW1 + 3 * m + 1] = gW1[1];
-    row[L.oW1 + 3 * m + 2] = gW1[2];
-    row[L.ob1 + m] = gb1;
-#pragma unroll
-    for (int i = 0; i < N; ++i) row[L.oW2 + i * L.H + m] = gW2[i];
   }
-  if (m < N) {  // b2 only feeds the value channel
-    float s = 0.f;
-    for (int pp = 0; pp < cnt; ++pp) s += sA[m][pp];
-    row[L.ob2 + m] = s;
+  float* mine = s_acc + (size_t)grp * (4 + N) * HB;
+  mine[0 * HB + m] = gW1[0];
+  mine[1 * HB + m] = gW1[1];
+  mine[2 * HB + m] = gW1[2];
+  mine[3 * HB + m] = gb1;
+#pragma unroll
+  for (int i = 0; i < N; ++i) mine[(4 + i) * HB + m] = gW2[i];
+  __syncthreads();
+  float* row = part + (row0 + blockIdx.x) * part_stride;
+  if (grp == 0 && m < L.H) {
+    float tot[4 + N];
+#pragma unroll
+    for (int k = 0; k < 4 + N; ++k) {
+      float sum = 0.f;
+      for (int g2 = 0; g2 < PS; ++g2) sum += s_acc[((size_t)g2 * (4 + N) + k) * HB + m];
+      tot[k] = sum;
+    }
+    row[L.oW1 + 3 * m] = tot[0];
+    row[L.oW1 + 3 * m + 1] = tot[1];
+    row[L.oW1 + 3 * m + 2] = tot[2];
+    row[L.ob1 + m] = tot[3];
+#pragma unroll
+    for (int i = 0; i < N; ++i) row[L.oW2 + i * L.H + m] = tot[4 + i];
+  }
+  if (threadIdx.x < N) {  // b2 only feeds the value channel
+    float sum = 0.f;
+    for (int pp = 0; pp < cnt; ++pp) sum += sA[threadIdx.x][pp];
+    row[L.ob2 + threadIdx.x] = sum;
   }
 }
 
 // ================================================================== post network + PDE + loss
-// lane = collocation point, one wave per block (a block owns one partial row).
+// Point kernel: lane = collocation point (scalar weights), 4 tiles per block.
 // MODE 0: forward only  -> u, residual
-// MODE 1: reverse only, cotangents (ubar, rbar) read from memory (autograd path)
-// MODE 2: forward + loss + reverse in one pass (training step)
+// MODE 1: reverse only: cotangents (ubar, rbar) come from memory (autograd path) -> qbar
+// MODE 2: forward + analytic targets + squared error (loss sums into the tile's partial row)
+//         + reverse -> qbar; the per-point cotangents (ubar, rbar-scale) are left in ub_out[2][B]
+// The weight gradients of W3/b3/W4/b4 are NOT formed here (they would need ~300 cross-lane
+// reductions per wave): k_post_wg below forms them with lane = hidden unit.
+template <int N, int NCH>
+__device__ __forceinline__ void post_cotangents(float (&gb)[NCH], float& gw4, const float (&g)[NCH],
+                                                const float (&ub)[NCH], const float z, const float w4) {
+  const float d1 = 1.f - z * z;
+  gw4 = ub[0] * z;
+  gb[0] = ub[0] * d1;
+  if constexpr (NCH == 6) {
+    const float d2 = -2.f * z * d1;
+    const float d3 = -2.f * (d1 * d1 + z * d2);
+    const float gx2 = g[2] * g[2], gy2 = g[3] * g[3];
+    const float lin = ub[1] * g[1] + ub[2] * g[2] + ub[3] * g[3];
+    gw4 += d1 * lin + ub[4] * (d2 * gx2 + d1 * g[4]) + ub[5] * (d2 * gy2 + d1 * g[5]);
+    gb[0] += d2 * lin + ub[4] * (d3 * gx2 + d2 * g[4]) + ub[5] * (d3 * gy2 + d2 * g[5]);
+    gb[1] = ub[1] * d1;
+    gb[2] = ub[2] * d1 + 2.f * ub[4] * d2 * g[2];
+    gb[3] = ub[3] * d1 + 2.f * ub[5] * d2 * g[3];
+    gb[4] = ub[4] * d1;
+    gb[5] = ub[5] * d1;
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) gb[c] *= w4;
+}
+
+template <int NCH>
+__device__ __forceinline__ void expand_ub(float (&ub)[NCH], float ub0, float gsc, const QcPde& pde) {
+  ub[0] = ub0;
+  if constexpr (NCH == 6) {
+    ub[1] = gsc;
+    ub[2] = gsc * pde.vx;
+    ub[3] = gsc * pde.vy;
+    ub[4] = -pde.D * gsc;
+    ub[5] = -pde.D * gsc;
+  }
+}
+
 template <int N, int NCH, int MODE>
-__global__ void __launch_bounds__(64) k_post(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
-                                             QcPde pde, const float* __restrict__ qjets,
-                                             float* __restrict__ out_u, float* __restrict__ out_res,
-                                             const float* __restrict__ in_ubar, const float* __restrict__ in_rbar,
-                                             float* __restrict__ qbar, float* __restrict__ part,
-                                             int64_t part_stride, int64_t row0, int64_t B) {
-  const int lane = threadIdx.x;
-  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+__global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+                                              QcPde pde, const float* __restrict__ qjets,
+                                              float* __restrict__ out_u, float* __restrict__ out_res,
+                                              const float* __restrict__ in_ubar, const float* __restrict__ in_rbar,
+                                              float* __restrict__ qbar, float* __restrict__ part,
+                                              int64_t part_stride, int64_t row0, int64_t B) {
+  // block = 4 waves on one 64-point tile; wave w owns a quarter of the hidden units
+  __shared__ float s_buf[QC_MS][NCH * N][64];   // partial u jets first (NCH rows), partial qbar later
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = blockIdx.x;
+  const int64_t p = tile * 64 + lane;
   const bool live = p < B;
   const int64_t pc = live ? p : B - 1;
   float q[NCH][N];
@@ -195,23 +275,22 @@ __global__ void __launch_bounds__(64) k_post(const float* __restrict__ X, const 
   const float* W3 = prm + L.oW3;
   const float* b3 = prm + L.ob3;
   const float* W4 = prm + L.oW4;
+  const int hq = (L.H + QC_MS - 1) / QC_MS;
+  const int m0 = wave * hq, m1 = (m0 + hq) < L.H ? (m0 + hq) : L.H;
 
-  float ub[NCH];  // cotangents of the u channels
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) ub[c] = 0.f;
-
+  float ub0 = 0.f, gsc = 0.f;  // cotangent of u, and of the residual
   if constexpr (MODE == 0 || MODE == 2) {
     float u[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) u[c] = 0.f;
-    for (int m = 0; m < L.H; ++m) {
+    for (int m = m0; m < m1; ++m) {
       float g[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        float s = (c == 0) ? b3[m] : 0.f;
+        float sum = (c == 0) ? b3[m] : 0.f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) s = fmaf(W3[m * N + i], q[c][i], s);
-        g[c] = s;
+        for (int i = 0; i < N; ++i) sum = fmaf(W3[m * N + i], q[c][i], sum);
+        g[c] = sum;
       }
       const float z = qc_tanh(g[0]);
       const float w4 = W4[m];
@@ -225,125 +304,182 @@ __global__ void __launch_bounds__(64) k_post(const float* __restrict__ X, const 
         u[5] = fmaf(w4, d2 * g[3] * g[3] + d1 * g[5], u[5]);
       }
     }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) s_buf[wave][c][lane] = u[c];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      u[c] = (s_buf[0][c][lane] + s_buf[1][c][lane]) + (s_buf[2][c][lane] + s_buf[3][c][lane]);
+    __syncthreads();   // s_buf is reused for the qbar partials below
     u[0] += prm[L.ob4];
-    const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
     float res = 0.f;
     if constexpr (NCH == 6) res = u[1] + pde.vx * u[2] + pde.vy * u[3] - pde.D * (u[4] + u[5]);
     if constexpr (MODE == 0) {
-      if (live) {
+      if (live && wave == 0) {
         if (out_u) out_u[p] = u[0];
         if constexpr (NCH == 6)
           if (out_res) out_res[p] = res;
       }
       return;
-    }
-    if constexpr (MODE == 2) {
-      float* row = part + (row0 + blockIdx.x) * part_stride;
+    } else {
+      const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
+      float* row = part + (row0 + tile) * part_stride;
       if constexpr (NCH == 6) {
         const float e = live ? res - analytic_r(t, x, y, pde.D, pde.vx, pde.vy) : 0.f;
-        const float gsc = pde.w_res * e;
-        ub[1] = gsc;
-        ub[2] = gsc * pde.vx;
-        ub[3] = gsc * pde.vy;
-        ub[4] = -pde.D * gsc;
-        ub[5] = -pde.D * gsc;
-        const float ls = qc_wave_sum_to_lane63(e * e * pde.inv_n_res);
-        if (lane == 63) {
-          row[L.NP + 0] = ls;
-          row[L.NP + 1] = 0.f;
-          row[L.NP + 2] = 0.f;
+        gsc = pde.w_res * e;
+        if (wave == 0) {
+          const float ls = qc_wave_sum_to_lane63(e * e * pde.inv_n_res);
+          if (lane == 63) {
+            row[L.NP + 0] = ls;
+            row[L.NP + 1] = 0.f;
+            row[L.NP + 2] = 0.f;
+          }
         }
       } else {
         const bool seg_a = p < pde.n_seg_a;
         const float e = live ? u[0] - analytic_u(t, x, y) : 0.f;
-        ub[0] = (seg_a ? pde.w_val_a : pde.w_val_b) * e;
-        const float la = qc_wave_sum_to_lane63(seg_a ? e * e * pde.inv_n_a : 0.f);
-        const float lb = qc_wave_sum_to_lane63(seg_a ? 0.f : e * e * pde.inv_n_b);
-        if (lane == 63) {
-          row[L.NP + 0] = 0.f;
-          row[L.NP + 1] = lb;  // column order: residual, BC, IC; segment a = IC, b = BC
-          row[L.NP + 2] = la;
+        ub0 = (seg_a ? pde.w_val_a : pde.w_val_b) * e;
+        if (wave == 0) {
+          const float la = qc_wave_sum_to_lane63(seg_a ? e * e * pde.inv_n_a : 0.f);
+          const float lb = qc_wave_sum_to_lane63(seg_a ? 0.f : e * e * pde.inv_n_b);
+          if (lane == 63) {
+            row[L.NP + 0] = 0.f;
+            row[L.NP + 1] = lb;  // column order: residual, BC, IC; segment a = IC, b = BC
+            row[L.NP + 2] = la;
+          }
         }
+      }
+      if (live && wave == 0) {  // hand the per-point cotangents to k_post_wg
+        out_u[p] = ub0;
+        if constexpr (NCH == 6) out_res[p] = gsc;
       }
     }
   }
   if constexpr (MODE == 1) {
-    ub[0] = (live && in_ubar) ? in_ubar[pc] : 0.f;
-    if constexpr (NCH == 6) {
-      const float rb = (live && in_rbar) ? in_rbar[pc] : 0.f;
-      ub[1] = rb;
-      ub[2] = rb * pde.vx;
-      ub[3] = rb * pde.vy;
-      ub[4] = -pde.D * rb;
-      ub[5] = -pde.D * rb;
-    }
+    ub0 = (live && in_ubar) ? in_ubar[pc] : 0.f;
+    if constexpr (NCH == 6) gsc = (live && in_rbar) ? in_rbar[pc] : 0.f;
   }
-
   if constexpr (MODE == 1 || MODE == 2) {
-    float* row = part + (row0 + blockIdx.x) * part_stride;
+    float ub[NCH];
+    expand_ub<NCH>(ub, ub0, gsc, pde);
     float qb[NCH][N];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
       for (int i = 0; i < N; ++i) qb[c][i] = 0.f;
-    for (int m = 0; m < L.H; ++m) {
+    for (int m = m0; m < m1; ++m) {
       float g[NCH];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        float s = (c == 0) ? b3[m] : 0.f;
+        float sum = (c == 0) ? b3[m] : 0.f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) s = fmaf(W3[m * N + i], q[c][i], s);
-        g[c] = s;
+        for (int i = 0; i < N; ++i) sum = fmaf(W3[m * N + i], q[c][i], sum);
+        g[c] = sum;
       }
       const float z = qc_tanh(g[0]);
-      const float w4 = W4[m];
-      const float d1 = 1.f - z * z;
-      float gb[NCH];
-      float gw4 = ub[0] * z;
-      gb[0] = ub[0] * d1;
-      if constexpr (NCH == 6) {
-        const float d2 = -2.f * z * d1;
-        const float d3 = -2.f * (d1 * d1 + z * d2);
-        const float gx2 = g[2] * g[2], gy2 = g[3] * g[3];
-        gw4 += d1 * (ub[1] * g[1] + ub[2] * g[2] + ub[3] * g[3]) + ub[4] * (d2 * gx2 + d1 * g[4]) +
-               ub[5] * (d2 * gy2 + d1 * g[5]);
-        gb[0] += d2 * (ub[1] * g[1] + ub[2] * g[2] + ub[3] * g[3]) + ub[4] * (d3 * gx2 + d2 * g[4]) +
-                 ub[5] * (d3 * gy2 + d2 * g[5]);
-        gb[1] = ub[1] * d1;
-        gb[2] = ub[2] * d1 + 2.f * ub[4] * d2 * g[2];
-        gb[3] = ub[3] * d1 + 2.f * ub[5] * d2 * g[3];
-        gb[4] = ub[4] * d1;
-        gb[5] = ub[5] * d1;
-      }
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) gb[c] *= w4;
+      float gb[NCH], gw4;
+      post_cotangents<N, NCH>(gb, gw4, g, ub, z, W4[m]);
 #pragma unroll
       for (int i = 0; i < N; ++i) {
         const float w3 = W3[m * N + i];
-        float gw3 = 0.f;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          qb[c][i] = fmaf(w3, gb[c], qb[c][i]);
-          gw3 = fmaf(gb[c], q[c][i], gw3);
-        }
-        gw3 = qc_wave_sum_to_lane63(gw3);
-        if (lane == 63) row[L.oW3 + m * N + i] = gw3;
-      }
-      const float r_b3 = qc_wave_sum_to_lane63(gb[0]);
-      const float r_w4 = qc_wave_sum_to_lane63(gw4);
-      if (lane == 63) {
-        row[L.ob3 + m] = r_b3;
-        row[L.oW4 + m] = r_w4;
+        for (int c = 0; c < NCH; ++c) qb[c][i] = fmaf(w3, gb[c], qb[c][i]);
       }
     }
-    const float r_b4 = qc_wave_sum_to_lane63(ub[0]);
-    if (lane == 63) row[L.ob4] = r_b4;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) s_buf[wave][c * N + i][lane] = qb[c][i];
+    __syncthreads();
     if (live) {
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int i = 0; i < N; ++i) qbar[((int64_t)c * N + i) * B + p] = qb[c][i];
+      for (int f = wave; f < NCH * N; f += QC_MS)
+        qbar[(int64_t)f * B + p] = (s_buf[0][f][lane] + s_buf[1][f][lane]) + (s_buf[2][f][lane] + s_buf[3][f][lane]);
     }
+  }
+}
+
+// Weight gradients of the post network: lane = hidden unit m (owns row m of W3, b3[m], W4[m]); the
+// block walks its 64-point tile, reading the tile's <Z> jets and per-point cotangents from LDS as
+// broadcasts.  No cross-lane reduction; one partial row per tile.
+template <int N, int NCH>
+__global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, const float* __restrict__ qjets,
+                          const float* __restrict__ ubar, const float* __restrict__ rbar,
+                          float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B, int HB, int PS) {
+  __shared__ float sQ[NCH * N][64];
+  __shared__ float sU[2][64];
+  extern __shared__ float s_acc[];  // [PS][N + 2][HB]
+  const int64_t base = (int64_t)blockIdx.x * 64;
+  const int cnt = (int)((B - base) < 64 ? (B - base) : 64);
+  for (int i = threadIdx.x; i < NCH * N * 64; i += blockDim.x) {
+    const int f = i >> 6, pp = i & 63;
+    sQ[f][pp] = pp < cnt ? qjets[(int64_t)f * B + base + pp] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+    const int k = i >> 6, pp = i & 63;
+    const float* src = k == 0 ? ubar : rbar;
+    sU[k][pp] = (pp < cnt && src != nullptr) ? src[base + pp] : 0.f;
+  }
+  __syncthreads();
+  const int grp = threadIdx.x / HB, m = threadIdx.x % HB;
+  const int per = 64 / PS;
+  const int p0 = grp * per, p1 = (p0 + per) < cnt ? (p0 + per) : cnt;
+  float gW3[N], gb3 = 0.f, gW4 = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) gW3[i] = 0.f;
+  if (m < L.H) {
+    float w3[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) w3[i] = prm[L.oW3 + m * N + i];
+    const float b3m = prm[L.ob3 + m], w4 = prm[L.oW4 + m];
+    for (int pp = p0; pp < p1; ++pp) {
+      float g[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float sum = (c == 0) ? b3m : 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) sum = fmaf(w3[i], sQ[c * N + i][pp], sum);
+        g[c] = sum;
+      }
+      const float z = qc_tanh(g[0]);
+      float ub[NCH];
+      expand_ub<NCH>(ub, sU[0][pp], sU[1][pp], pde);
+      float gb[NCH], gw4;
+      post_cotangents<N, NCH>(gb, gw4, g, ub, z, w4);
+      gW4 += gw4;
+      gb3 += gb[0];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        float sum = gW3[i];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) sum = fmaf(gb[c], sQ[c * N + i][pp], sum);
+        gW3[i] = sum;
+      }
+    }
+  }
+  float* mine = s_acc + (size_t)grp * (N + 2) * HB;
+#pragma unroll
+  for (int i = 0; i < N; ++i) mine[i * HB + m] = gW3[i];
+  mine[N * HB + m] = gb3;
+  mine[(N + 1) * HB + m] = gW4;
+  __syncthreads();
+  float* row = part + (row0 + blockIdx.x) * part_stride;
+  if (grp == 0 && m < L.H) {
+    float tot[N + 2];
+#pragma unroll
+    for (int k = 0; k < N + 2; ++k) {
+      float sum = 0.f;
+      for (int g2 = 0; g2 < PS; ++g2) sum += s_acc[((size_t)g2 * (N + 2) + k) * HB + m];
+      tot[k] = sum;
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) row[L.oW3 + m * N + i] = tot[i];
+    row[L.ob3 + m] = tot[N];
+    row[L.oW4 + m] = tot[N + 1];
+  }
+  if (threadIdx.x == 0) {
+    float sum = 0.f;
+    for (int pp = 0; pp < cnt; ++pp) sum += sU[0][pp];
+    row[L.ob4] = sum;
   }
 }
 
@@ -361,9 +497,15 @@ __global__ void __launch_bounds__(64) k_post(const float* __restrict__ X, const 
     default: return QC_ERR_UNSUPPORTED;                                                            \
   }
 
+static inline void hidden_geometry(int H, int* HB, int* PS) {
+  *HB = 64 * qc_ceil_div(H, 64);
+  int ps = 1024 / *HB;
+  *PS = ps >= 4 ? 4 : (ps >= 2 ? 2 : 1);
+}
+
 int qc_mlp_pre_fwd(const float* X, const float* prm, QcLayout L, float* ajets, int64_t B, int nch,
                    hipStream_t st) {
-  const int grid = qc_ceil_div(B, 256);
+  const int grid = qc_ceil_div(B, 64);
 #define CALL(NN)                                                                                   \
   if (nch == 6) hipLaunchKernelGGL((k_pre_fwd<NN, 6>), dim3(grid), dim3(256), 0, st, X, prm, L, ajets, B); \
   else hipLaunchKernelGGL((k_pre_fwd<NN, 1>), dim3(grid), dim3(256), 0, st, X, prm, L, ajets, B);
@@ -375,13 +517,16 @@ int qc_mlp_pre_fwd(const float* X, const float* prm, QcLayout L, float* ajets, i
 int qc_mlp_pre_bwd(const float* X, const float* prm, QcLayout L, const float* abar, float* part,
                    int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t st) {
   const int grid = qc_ceil_div(B, 64);
-  const int threads = 64 * qc_ceil_div(L.H > L.n ? L.H : L.n, 64);
-  if (threads > 1024) return QC_ERR_UNSUPPORTED;
-#define CALL(NN)                                                                                          \
-  if (nch == 6) hipLaunchKernelGGL((k_pre_bwd<NN, 6>), dim3(grid), dim3(threads), 0, st, X, prm, L, abar, \
-                                   part, part_stride, row0, B);                                           \
-  else hipLaunchKernelGGL((k_pre_bwd<NN, 1>), dim3(grid), dim3(threads), 0, st, X, prm, L, abar, part,    \
-                          part_stride, row0, B);
+  if (L.H > 1024 || L.n > 64) return QC_ERR_UNSUPPORTED;
+  int HB, PS;
+  hidden_geometry(L.H, &HB, &PS);
+  const int threads = HB * PS;
+  const size_t sh = (size_t)PS * (4 + L.n) * HB * sizeof(float);
+#define CALL(NN)                                                                                               \
+  if (nch == 6) hipLaunchKernelGGL((k_pre_bwd<NN, 6>), dim3(grid), dim3(threads), sh, st, X, prm, L, abar, part, \
+                                   part_stride, row0, B, HB, PS);                                              \
+  else hipLaunchKernelGGL((k_pre_bwd<NN, 1>), dim3(grid), dim3(threads), sh, st, X, prm, L, abar, part,         \
+                          part_stride, row0, B, HB, PS);
   QC_MLP_DISPATCH(L.n, CALL)
 #undef CALL
   return QC_OK;
@@ -390,22 +535,33 @@ int qc_mlp_pre_bwd(const float* X, const float* prm, QcLayout L, const float* ab
 int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pde, const float* qjets,
                 float* out_u, float* out_res, const float* in_ubar, const float* in_rbar, float* qbar,
                 float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t st) {
-  const int grid = qc_ceil_div(B, 64);
+  const int tiles = qc_ceil_div(B, 64);
+  if (L.H > 1024) return QC_ERR_UNSUPPORTED;
+  int HB, PS;
+  hidden_geometry(L.H, &HB, &PS);
+  const size_t sh = (size_t)PS * (L.n + 2) * HB * sizeof(float);
+  // cotangent sources of the weight-gradient kernel: given (mode 1) or produced by the point kernel (mode 2)
+  const float* ub_src = mode == 1 ? in_ubar : out_u;
+  const float* rb_src = mode == 1 ? in_rbar : out_res;
 #define LAUNCH(NN, CC, MM)                                                                              \
-  hipLaunchKernelGGL((k_post<NN, CC, MM>), dim3(grid), dim3(64), 0, st, X, prm, L, pde, qjets, out_u,    \
+  hipLaunchKernelGGL((k_post<NN, CC, MM>), dim3(tiles), dim3(256), 0, st, X, prm, L, pde, qjets, out_u,  \
                      out_res, in_ubar, in_rbar, qbar, part, part_stride, row0, B)
+#define LAUNCH_WG(NN, CC)                                                                               \
+  hipLaunchKernelGGL((k_post_wg<NN, CC>), dim3(tiles), dim3(HB * PS), sh, st, prm, L, pde, qjets,        \
+                     ub_src, (CC == 6 ? rb_src : nullptr), part, part_stride, row0, B, HB, PS)
 #define CALL(NN)                                                         \
   if (nch == 6) {                                                        \
     if (mode == 0) LAUNCH(NN, 6, 0);                                     \
-    else if (mode == 1) LAUNCH(NN, 6, 1);                                \
-    else LAUNCH(NN, 6, 2);                                               \
+    else if (mode == 1) { LAUNCH(NN, 6, 1); LAUNCH_WG(NN, 6); }          \
+    else { LAUNCH(NN, 6, 2); LAUNCH_WG(NN, 6); }                         \
   } else {                                                               \
     if (mode == 0) LAUNCH(NN, 1, 0);                                     \
-    else if (mode == 1) LAUNCH(NN, 1, 1);                                \
-    else LAUNCH(NN, 1, 2);                                               \
+    else if (mode == 1) { LAUNCH(NN, 1, 1); LAUNCH_WG(NN, 1); }          \
+    else { LAUNCH(NN, 1, 2); LAUNCH_WG(NN, 1); }                         \
   }
   QC_MLP_DISPATCH(L.n, CALL)
 #undef CALL
 #undef LAUNCH
+#undef LAUNCH_WG
   return QC_OK;
 }
