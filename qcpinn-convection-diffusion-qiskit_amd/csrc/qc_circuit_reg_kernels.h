@@ -102,6 +102,7 @@ struct StatProg {
       s = tr.s;
     }
     qc_static_gate<N, 1, false, g.op, g.ba, g.bb, g.slot>(v, c, s, umat);
+    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from interleaving whole gates (register pressure)
   }
   template <int... Is>
   __device__ static __forceinline__ void fwd_all(SV<N> (&v)[1], const QcTrig* __restrict__ trig,
@@ -112,10 +113,12 @@ struct StatProg {
                                              const float* __restrict__ umat, int) {
     fwd_all(v, trig, umat, std::make_integer_sequence<int, SP::G>{});
   }
+  // Reverse sweep.  Parameter slots are compile-time constants here, so the wave totals of the
+  // gradient terms stay in registers (gacc[slot], valid in lane 63) and reach LDS once, after the
+  // sweep, instead of one LDS read-modify-write round trip per gate.
   template <int J>
   __device__ static __forceinline__ void bwd_one(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, float* __restrict__ acc_wave,
-                                                 int lane) {
+                                                 const float* __restrict__ umat, float (&gacc)[SP::P > 0 ? SP::P : 1]) {
     constexpr int I = SP::G - 1 - J;
     constexpr SGate g = SP::g[I];
     float c = 1.f, s = 0.f;
@@ -123,21 +126,27 @@ struct StatProg {
       const QcTrig tr = trig[I];
       c = tr.c;
       s = tr.s;
-      const float gr = qc_wave_sum_to_lane63(qc_static_grad<N, g.op, g.ba, g.bb>(cl[1], cl[0]));
-      if (lane == 63) acc_wave[g.slot] += gr;
+      gacc[g.slot] += qc_wave_sum_to_lane63(qc_static_grad<N, g.op, g.ba, g.bb>(cl[1], cl[0]));
     }
     qc_static_gate<N, 2, true, g.op, g.ba, g.bb, g.slot>(cl, c, s, umat);
+    __builtin_amdgcn_sched_barrier(0);
   }
   template <int... Js>
   __device__ static __forceinline__ void bwd_all(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, float* __restrict__ acc_wave,
-                                                 int lane, std::integer_sequence<int, Js...>) {
-    (bwd_one<Js>(cl, trig, umat, acc_wave, lane), ...);
+                                                 const float* __restrict__ umat, float (&gacc)[SP::P > 0 ? SP::P : 1],
+                                                 std::integer_sequence<int, Js...>) {
+    (bwd_one<Js>(cl, trig, umat, gacc), ...);
   }
   __device__ static __forceinline__ void bwd(SV<N> (&cl)[2], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
                                              const float* __restrict__ umat, int, float* __restrict__ acc_wave,
                                              int lane) {
-    bwd_all(cl, trig, umat, acc_wave, lane, std::make_integer_sequence<int, SP::G>{});
+    float gacc[SP::P > 0 ? SP::P : 1];
+#pragma unroll
+    for (int k = 0; k < (SP::P > 0 ? SP::P : 1); ++k) gacc[k] = 0.f;
+    bwd_all(cl, trig, umat, gacc, std::make_integer_sequence<int, SP::G>{});
+#pragma unroll
+    for (int k = 0; k < SP::P; ++k)
+      if (lane == 63) acc_wave[k] += gacc[k];   // lane 63 holds the wave totals
   }
 };
 
@@ -149,6 +158,42 @@ __device__ __forceinline__ void load_sincos(float (&ca)[N], float (&sa)[N], cons
     const float h = 0.5f * a[(int64_t)w * B + p];
     sincosf(h, &sa[w], &ca[w]);
   }
+}
+
+// Embedding series of channel `ch`'s direction for this lane's point: P0 = phi, P1 = d phi,
+// P2 = d2 phi (only as far as the channel needs).
+template <int N>
+__device__ __forceinline__ void channel_series(float (&P0)[1 << N], float (&P1)[1 << N], float (&P2)[1 << N],
+                                               int ch, const float* __restrict__ ajets, int64_t B, int64_t pc) {
+  float ca[N], sa[N], da[N], dda[N];
+  load_sincos<N>(ca, sa, ajets, B, pc);
+  const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);  // channel holding the first derivative
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    da[w] = ch >= 1 ? ajets[((int64_t)dirch * N + w) * B + pc] : 0.f;
+    dda[w] = ch >= 4 ? ajets[((int64_t)ch * N + w) * B + pc] : 0.f;
+  }
+  if (ch == 0) qc_embed_series<N, 0>(P0, P1, P2, ca, sa, da, dda);
+  else if (ch <= 3) qc_embed_series<N, 1>(P0, P1, P2, ca, sa, da, dda);
+  else qc_embed_series<N, 2>(P0, P1, P2, ca, sa, da, dda);
+}
+
+// Initial vector of channel `ch`.
+template <int N>
+__device__ __forceinline__ void build_channel(SV<N>& v, int ch, const float* __restrict__ ajets, int64_t B,
+                                              int64_t pc) {
+  float P0[1 << N], P1[1 << N], P2[1 << N];
+  channel_series<N>(P0, P1, P2, ch, ajets, B, pc);
+  if (ch == 0) qc_phase_load<N>(v, P0);
+  else if (ch <= 3) qc_phase_load<N>(v, P1);
+  else qc_phase_load<N>(v, P2);
+}
+
+// Hides a pointer's provenance from the optimiser: loads through the result are not merged with
+// earlier loads, so values recomputed from them do not stay live in registers in between.
+__device__ __forceinline__ const float* qc_launder(const float* p) {
+  asm volatile("" : "+s"(p));
+  return p;
 }
 
 // ================================================================== value channel only
@@ -220,7 +265,11 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
   }
   PG::bwd(cl, prog, trig, umat, n_gates, smem + wave * n_params, lane);
   float T[N];
-  qc_embed_ip<N>(T, cl[1], P0);
+  {
+    float Q0[1 << N], Q1[1 << N], Q2[1 << N];
+    channel_series<N>(Q0, Q1, Q2, 0, qc_launder(angles), B, pc);
+    qc_embed_ip<N>(T, cl[1], Q0);
+  }
   if (live) {
 #pragma unroll
     for (int w = 0; w < N; ++w) d_angles[(int64_t)w * B + p] = T[w];
@@ -233,32 +282,6 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
 }
 
 // ================================================================== six derivative channels
-// Builds the initial vector of channel `ch` for this lane's point.  P0/P1/P2 are left holding
-// the embedding series of the channel's direction (needed again by the backward kernel).
-template <int N>
-__device__ __forceinline__ void build_channel(SV<N>& v, float (&P0)[1 << N], float (&P1)[1 << N],
-                                              float (&P2)[1 << N], int ch, const float* __restrict__ ajets,
-                                              int64_t B, int64_t pc) {
-  float ca[N], sa[N], da[N], dda[N];
-  load_sincos<N>(ca, sa, ajets, B, pc);
-  const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);  // channel holding the first derivative
-#pragma unroll
-  for (int w = 0; w < N; ++w) {
-    da[w] = ch >= 1 ? ajets[((int64_t)dirch * N + w) * B + pc] : 0.f;
-    dda[w] = ch >= 4 ? ajets[((int64_t)ch * N + w) * B + pc] : 0.f;
-  }
-  if (ch == 0) {
-    qc_embed_series<N, 0>(P0, P1, P2, ca, sa, da, dda);
-    qc_phase_load<N>(v, P0);
-  } else if (ch <= 3) {
-    qc_embed_series<N, 1>(P0, P1, P2, ca, sa, da, dda);
-    qc_phase_load<N>(v, P1);
-  } else {
-    qc_embed_series<N, 2>(P0, P1, P2, ca, sa, da, dda);
-    qc_phase_load<N>(v, P2);
-  }
-}
-
 template <class PG>
 __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates,
@@ -274,8 +297,7 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
   const int64_t pc = p < B ? p : B - 1;
 
   SV<N> v[1];
-  float P0[1 << N], P1[1 << N], P2[1 << N];
-  build_channel<N>(v[0], P0, P1, P2, ch, ajets, B, pc);
+  build_channel<N>(v[0], ch, ajets, B, pc);
   PG::fwd(v, prog, trig, umat, n_gates);
 
   float t[1 << N], q[N];
@@ -313,8 +335,11 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
   }
 }
 
+#ifndef QC_JB_WAVES
+#define QC_JB_WAVES 3
+#endif
 template <class PG>
-__global__ void __launch_bounds__(384) k_jets_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+__global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates, int n_params,
                                                   const float* __restrict__ ajets, const float* __restrict__ qbar,
                                                   float* __restrict__ abar, float* __restrict__ part,
@@ -333,10 +358,9 @@ __global__ void __launch_bounds__(384) k_jets_bwd(const QcGate* __restrict__ pro
   const int64_t pc = live ? p : B - 1;
 
   SV<N> cl[2];
-  float P0[1 << N], P1[1 << N], P2[1 << N];
   {
     SV<N> v[1];
-    build_channel<N>(v[0], P0, P1, P2, ch, ajets, B, pc);
+    build_channel<N>(v[0], ch, ajets, B, pc);
     PG::fwd(v, prog, trig, umat, n_gates);
     cl[0] = v[0];
   }
@@ -369,7 +393,8 @@ __global__ void __launch_bounds__(384) k_jets_bwd(const QcGate* __restrict__ pro
       cl[1].re[k] = d[k] * cl[0].re[k];
       cl[1].im[k] = d[k] * cl[0].im[k];
     }
-    for (int c = 1; c < QC_NCH; ++c) {
+#pragma unroll 1
+    for (int c = 1; c < QC_NCH; ++c) {   // one channel at a time: keeps the live set at one vector
       dvec(c, d);
       const float* other = s_chi + c * A2 * 64;
 #pragma unroll
@@ -398,7 +423,10 @@ __global__ void __launch_bounds__(384) k_jets_bwd(const QcGate* __restrict__ pro
 
   PG::bwd(cl, prog, trig, umat, n_gates, s_acc + ch * n_params, lane);
 
-  // ---- cotangents of the angle jets: Im<Lambda| X_w |phi> against the embedding series
+  // ---- cotangents of the angle jets: Im<Lambda| X_w |phi> against the embedding series, which is
+  // rebuilt here (exact, and cheaper than carrying 3 * 2^n registers through the sweep)
+  float P0[1 << N], P1[1 << N], P2[1 << N];
+  channel_series<N>(P0, P1, P2, ch, qc_launder(ajets), B, pc);
   float* buf = s_chi + ch * 3 * N * 64;  // [3][N][64] per wave
   float T[N];
   if (ch == 0) {
