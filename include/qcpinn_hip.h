@@ -108,6 +108,13 @@ int qc_adam_step(float* flat_dev, int NP, float* params_dev, float* m_dev, float
                  const qc_opt_hyper* hp, float* hist_dev, int hist_cap, const qc_program* prog, int theta_off,
                  void* trig_dev, void* stream);
 
+/* ---- the three uniform batches of a step (trainer/diffusion_train.py:9-20,34-36: IC t=0 face, BC1 x=0
+ * face, residual in [0,1]^3; data/diffusion_dataset.py:12-19) drawn on device with Philox4x32-10 keyed by
+ * (seed, step, batch) and indexed by the GLOBAL point index off_* + i: ranks of a data-parallel run fill
+ * disjoint shards of the batch a single GPU would draw.  X_val holds the IC points first, then BC. */
+int qc_sample_collocation(float* X_res_dev, int64_t n_res, int64_t off_res, float* X_val_dev, int64_t n_ic,
+                          int64_t off_ic, int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, void* stream);
+
 /* ---- one whole training step (trainer/diffusion_train.py:30-49,81-90) on resident batches:
  * residual batch through the 6-channel pipeline, IC+BC batch through the value pipeline,
  * row reduction, then (phase 2) clip + Adam + scheduler.  With `phases` = 1 it stops after the
@@ -127,10 +134,15 @@ typedef struct qc_step_desc {
   float* flat_dev;                                                                       /* NP+3 */
   qc_pde pde;
   qc_opt_hyper hyper;
+  /* on-device sampler (QC_PHASE_SAMPLE): global index of this rank's first point in each batch */
+  int64_t n_ic;                 /* leading IC points of the value batch (== pde.n_seg_a) */
+  int64_t sample_off_res, sample_off_ic, sample_off_bc;
+  uint64_t sample_seed, sample_step;
 } qc_step_desc;
 
 #define QC_PHASE_GRADS 1
 #define QC_PHASE_UPDATE 2
+#define QC_PHASE_SAMPLE 4 /* fill X_res / X_val first (see qc_sample_collocation) */
 int qc_fused_pinn_residual_step(const qc_step_desc* desc, int phases, void* stream);
 
 #ifdef __cplusplus

@@ -226,6 +226,14 @@ int qc_adam_step(float* flat, int NP, float* prm, float* m, float* v, void* stat
   return after_launch();
 }
 
+int qc_sample_collocation(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
+                          int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, void* stream) {
+  if (n_res < 0 || n_ic < 0 || n_bc < 0 || off_res < 0 || off_ic < 0 || off_bc < 0) return QC_ERR_ARG;
+  if ((n_res > 0 && !X_res) || (n_ic + n_bc > 0 && !X_val)) return QC_ERR_ARG;
+  qc_sample_launch(X_res, n_res, off_res, X_val, n_ic, off_ic, n_bc, off_bc, seed, step, (hipStream_t)stream);
+  return after_launch();
+}
+
 int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream) {
   if (!d || !d->prog || !d->trig_dev || !d->params_dev || !d->part_dev || !d->flat_dev) return QC_ERR_ARG;
   const int n = d->n, H = d->H;
@@ -241,6 +249,11 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
   const QcTrig* trig = (const QcTrig*)d->trig_dev;
   const QcPde pde = to_pde(&d->pde);
 
+  if (phases & QC_PHASE_SAMPLE) {
+    if ((rc = qc_sample_collocation((float*)d->X_res_dev, d->B_res, d->sample_off_res, (float*)d->X_val_dev, d->n_ic,
+                                    d->sample_off_ic, d->B_val - d->n_ic, d->sample_off_bc, d->sample_seed,
+                                    d->sample_step, st))) return rc;
+  }
   if (phases & QC_PHASE_GRADS) {
     if (d->B_res > 0) {
       if (!d->X_res_dev || !d->ajets_res_dev || !d->qjets_res_dev || !d->qbar_res_dev || !d->abar_res_dev)

@@ -81,3 +81,5 @@ int qc_opt_reduce_rows(const float* part, int64_t rows, int64_t stride, int ncol
 int qc_opt_adam(float* flat, int NP, float* prm, float* m, float* v, QcOptState* state, QcOptHyper hp,
                 float* hist, int hist_cap, const qc_program* pg, int theta_off, QcTrig* trig, hipStream_t);
 int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t);
+int qc_sample_launch(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
+                     int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, hipStream_t);

@@ -1,0 +1,66 @@
+// Collocation-point sampler: the three uniform batches of one training step in one launch.
+//
+// Replaces the three torch.rand draws + affine maps of the reference step
+// (trainer/diffusion_train.py:9-20 boxes, :34-36 order IC -> BC1 -> residual; data/diffusion_dataset.py:12-19
+// x = lo + (hi - lo) * rand).  Counter-based Philox4x32-10 keyed by (seed, step, batch id) and indexed
+// by the GLOBAL point index, so a data-parallel run draws exactly the points the single-GPU run draws
+// (each rank fills its shard of the same global batch) and no generator state lives on the host.
+#include "qc_internal.h"
+
+namespace {
+
+struct U4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = {hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0};
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return c;
+}
+
+__device__ __forceinline__ float u01(uint32_t v) { return (float)(v >> 8) * (1.0f / 16777216.0f); }  // [0,1)
+
+// segment 0: residual points in [0,1]^3; 1: IC points (t = 0); 2: BC1 points (x = 0)
+__global__ void __launch_bounds__(256) k_sample(float* __restrict__ X_res, int64_t n_res, int64_t off_res,
+                                                float* __restrict__ X_val, int64_t n_ic, int64_t off_ic,
+                                                int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int seg;
+  int64_t local, gidx;
+  float* dst;
+  if (i < n_res) {
+    seg = 0; local = i; gidx = off_res + local; dst = X_res + local * 3;
+  } else if (i < n_res + n_ic) {
+    seg = 1; local = i - n_res; gidx = off_ic + local; dst = X_val + local * 3;
+  } else if (i < n_res + n_ic + n_bc) {
+    seg = 2; local = i - n_res - n_ic; gidx = off_bc + local; dst = X_val + (n_ic + local) * 3;
+  } else {
+    return;
+  }
+  const U4 ctr = {(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)seg << 30)};
+  const U4 r = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float t = seg == 1 ? 0.f : u01(r.x);
+  const float x = seg == 2 ? 0.f : u01(r.y);
+  const float y = u01(r.z);
+  dst[0] = t;
+  dst[1] = x;
+  dst[2] = y;
+}
+
+}  // namespace
+
+int qc_sample_launch(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
+                     int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, hipStream_t st) {
+  const int64_t total = n_res + n_ic + n_bc;
+  if (total <= 0) return QC_OK;
+  hipLaunchKernelGGL(k_sample, dim3(qc_ceil_div(total, 256)), dim3(256), 0, st, X_res, n_res, off_res, X_val, n_ic,
+                     off_ic, n_bc, off_bc, seed, step);
+  return QC_OK;
+}

@@ -314,8 +314,20 @@ class FusedStep:
         d.flat_dev = self.flat_grad.data_ptr()
         d.pde = eng._pde(max(g_res, 1), max(g_ic, 1), max(g_bc, 1), n_ic)
         d.hyper = opt.hyper
+        d.n_ic = n_ic
+        d.sample_off_res = d.sample_off_ic = d.sample_off_bc = 0
+        d.sample_seed, d.sample_step = 0, 0
         self.desc = d
 
+    def set_sampler(self, seed: int, off_res: int = 0, off_ic: int = 0, off_bc: int = 0) -> None:
+        """On-device batches (QC_PHASE_SAMPLE): Philox stream `seed`; off_* = global index of this
+        rank's first point in each batch (data parallelism)."""
+        d = self.desc
+        d.sample_seed = seed & 0xFFFFFFFFFFFFFFFF
+        d.sample_off_res, d.sample_off_ic, d.sample_off_bc = off_res, off_ic, off_bc
+
     def run(self, phases: int = L.QC_PHASE_GRADS | L.QC_PHASE_UPDATE) -> None:
+        if phases & L.QC_PHASE_SAMPLE:
+            self.desc.sample_step += 1          # a fresh counter block per step
         L.check(self.eng.lib.qc_fused_pinn_residual_step(C.byref(self.desc), phases, _stream(self.eng.device)),
                 "qc_fused_pinn_residual_step")

@@ -15,13 +15,14 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libqcpinn_hip.so")
 
 QC_PHASE_GRADS = 1
 QC_PHASE_UPDATE = 2
+QC_PHASE_SAMPLE = 4
 
 # every symbol include/qcpinn_hip.h declares
 EXPORTS = (
     "qc_version", "qc_error_string", "qc_last_hip_error", "qc_program_create", "qc_program_destroy",
     "qc_trig_bytes", "qc_prepare_gates", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
-    "qc_fused_pinn_residual_step",
+    "qc_sample_collocation", "qc_fused_pinn_residual_step",
 )
 
 
@@ -57,6 +58,8 @@ class QcStepDesc(C.Structure):
         ("part_dev", C.c_void_p), ("part_stride", C.c_int64), ("part_rows_cap", C.c_int64),
         ("flat_dev", C.c_void_p),
         ("pde", QcPde), ("hyper", QcOptHyper),
+        ("n_ic", C.c_int64), ("sample_off_res", C.c_int64), ("sample_off_ic", C.c_int64),
+        ("sample_off_bc", C.c_int64), ("sample_seed", C.c_uint64), ("sample_step", C.c_uint64),
     ]
 
 
@@ -93,6 +96,7 @@ def load() -> C.CDLL:
                             i64, i32, vp]
     lib.qc_reduce_rows.argtypes = [fp, i64, i64, i32, fp, vp]
     lib.qc_adam_step.argtypes = [fp, i32, fp, fp, fp, vp, C.POINTER(QcOptHyper), fp, i32, vp, i32, vp, vp]
+    lib.qc_sample_collocation.argtypes = [fp, i64, i64, fp, i64, i64, i64, i64, C.c_uint64, C.c_uint64, vp]
     lib.qc_fused_pinn_residual_step.argtypes = [C.POINTER(QcStepDesc), i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

@@ -65,9 +65,14 @@ def _log_line(model, it, parts, lr, step_time, total_elapsed):
 # ---------------------------------------------------------------------------------------------
 class FusedTrainer:
     """Device-resident training state of one DVPDESolver: sampler boxes, optimiser record,
-    the fused-step descriptor.  ``step()`` = one reference iteration, no host synchronisation."""
+    the fused-step descriptor.  ``step()`` = one reference iteration, no host synchronisation.
 
-    def __init__(self, model, batch_size: int, capacity: int):
+    ``sampler="device"`` (default) draws the three batches inside the fused call with a counter-based
+    Philox generator indexed by the global point index (seeded once from torch's CPU generator, so
+    ``torch.manual_seed`` still controls the run); ``sampler="torch"`` uses three ``torch.rand`` calls
+    like the reference (IC -> BC -> residual)."""
+
+    def __init__(self, model, batch_size: int, capacity: int, sampler: str = "device"):
         dev = model._resolve_device(model.device)
         if dev is None or dev.type != "cuda":
             raise _lib.QcError("training a DVPDESolver needs a GPU (HIP kernels, no CPU fallback)")
@@ -85,6 +90,19 @@ class FusedTrainer:
         self.span = {k: box(k, dev)[1:2] - box(k, dev)[0:1] for k in ("ics", "bc1", "dom")}
         self.eng.refresh_gates()
         model._sync_fused_to_torch = self.sync_to_torch
+        if sampler not in ("device", "torch"):
+            raise ValueError("sampler must be 'device' or 'torch'")
+        self.sampler = sampler
+        self._explicit = False
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())        # every rank must draw the same seed
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([seed], dtype=torch.int64, device=dev)
+            dist.broadcast(t, 0)
+            seed = int(t.item())
+        self.fs.set_sampler(seed, shard_slice(batch_size, self.world, self.rank).start,
+                            shard_slice(n3, self.world, self.rank).start,
+                            shard_slice(n3, self.world, self.rank).start)
 
     # -- optimiser state: continue from the torch optimiser / scheduler objects of the model
     def _make_opt_state(self, capacity):
@@ -131,7 +149,12 @@ class FusedTrainer:
 
     # -- batches
     def sample(self):
-        """IC -> BC -> residual, uniform in the reference's boxes (trainer/diffusion_train.py:9-20,34-36)."""
+        """IC -> BC -> residual, uniform in the reference's boxes (trainer/diffusion_train.py:9-20,34-36).
+        With the device sampler this only arms the next ``step()``."""
+        self._explicit = False
+        if self.sampler == "device":
+            return
+        self._explicit = True
         fs, dev = self.fs, self.device
         if self.n_ic:
             fs.X_val[: self.n_ic] = self.lo["ics"] + self.span["ics"] * torch.rand(self.n_ic, 3, device=dev)
@@ -143,6 +166,7 @@ class FusedTrainer:
 
     def load_batches(self, X_ic, X_bc, X_res):
         """Use given GLOBAL batches (parity tests): this rank takes its contiguous shard."""
+        self._explicit = True
         fs, dev = self.fs, self.device
         s_ic = shard_slice(X_ic.shape[0], self.world, self.rank)
         s_bc = shard_slice(X_bc.shape[0], self.world, self.rank)
@@ -155,11 +179,12 @@ class FusedTrainer:
             fs.X_res[: self.B_res] = X_res[s_rs].to(dev)
 
     def step(self):
+        draw = 0 if self._explicit else _lib.QC_PHASE_SAMPLE
         if self.world == 1:
-            self.fs.run()
+            self.fs.run(draw | _lib.QC_PHASE_GRADS | _lib.QC_PHASE_UPDATE)
         else:
             import torch.distributed as dist
-            self.fs.run(_lib.QC_PHASE_GRADS)
+            self.fs.run(draw | _lib.QC_PHASE_GRADS)
             dist.all_reduce(self.fs.flat_grad)          # one small all-reduce: [grads | L_r, L_bc, L_ic]
             self.fs.run(_lib.QC_PHASE_UPDATE)
 

@@ -1,0 +1,81 @@
+"""Data-parallel FusedTrainer on the GPU: two ranks (both on cuda:0, gloo as the transport, since a
+single-GPU box cannot host two RCCL ranks) must reproduce the single-process loss history on the same
+global batches, and the device sampler must give both ranks disjoint shards of one global batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, ROOT, pkg
+
+pytestmark = pytest.mark.gpu
+
+
+def base_args(**kw):
+    a = {"batch_size": 64, "epochs": 20, "lr": 0.005, "seed": 1, "print_every": 1000, "num_qubits": 4,
+         "num_quantum_layers": 1, "classic_network": [3, 50, 1], "q_ansatz": "cascade", "shots": 1024,
+         "problem": "diffusion", "solver": "DV", "encoding": "None", "use_ibm_hardware": False}
+    a.update(kw)
+    return a
+
+
+class Log:
+    def print(self, *a):
+        pass
+
+    def get_output_dir(self):
+        return "/tmp"
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    z = np.load(os.path.join(GOLDEN, "train_cascade_n4_b64.npz"))
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    trainer = pkg("trainer.diffusion_train")
+    torch.manual_seed(1)
+    model = Solver(base_args(), Log(), device=dev)
+    steps = z["X_res"].shape[0]
+    batches = [tuple(torch.from_numpy(z[k][it]) for k in ("X_ic", "X_bc", "X_res")) for it in range(steps)]
+    trainer.train(model, batch_size=64, batches=batches)
+    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), np.array(model.loss_history))
+    np.save(os.path.join(out_dir, f"w_{rank}.npy"), torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy())
+    # device sampler: shards of one global batch
+    torch.manual_seed(5)
+    tr = trainer.FusedTrainer(model, 640, capacity=2)
+    tr.sample()
+    tr.step()
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"xres_{rank}.npy"), tr.fs.X_res[: tr.B_res].cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_matches_reference_history(tmp_path, gpu_device):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    z = np.load(os.path.join(GOLDEN, "train_cascade_n4_b64.npz"))
+    h0, h1 = (np.load(os.path.join(tmp_path, f"hist_{r}.npy")) for r in range(2))
+    assert np.array_equal(h0, h1)                                     # replicated optimiser state
+    assert np.abs(h0 - z["loss_history"]).max() < 1e-4 * max(1.0, np.abs(z["loss_history"]).max())
+    w0, w1 = (np.load(os.path.join(tmp_path, f"w_{r}.npy")) for r in range(2))
+    assert np.array_equal(w0, w1)
+    # sampler shards: same seed on both ranks, disjoint contiguous shards of the global index space
+    L = pkg("hip.lib")
+    x0, x1 = (np.load(os.path.join(tmp_path, f"xres_{r}.npy")) for r in range(2))
+    assert x0.shape == (320, 3) and x1.shape == (320, 3)
+    assert not np.array_equal(x0, x1)
+    both = np.concatenate([x0, x1])
+    assert len(np.unique(both[:, 0])) > 630

@@ -160,3 +160,44 @@ def test_cpu_input_fails_loudly(gpu_device, tmp_path):
     model = Solver(base_args(), Log(tmp_path), device=gpu_device)
     with pytest.raises(L.QcError):
         model(torch.rand(4, 3))
+
+
+def test_device_sampler_boxes_and_sharding(gpu_device):
+    """qc_sample_collocation: reference boxes (trainer/diffusion_train.py:9-20), uniform [0,1), and the
+    data-parallel property: shards indexed by global point index reproduce the single-GPU batch."""
+    L = pkg("hip.lib")
+    lib = L.load()
+    st = torch.cuda.current_stream(gpu_device).cuda_stream
+    n_res, n_ic, n_bc = 4099, 1365, 1365
+    Xr = torch.empty(n_res, 3, device=gpu_device)
+    Xv = torch.empty(n_ic + n_bc, 3, device=gpu_device)
+    L.check(lib.qc_sample_collocation(Xr.data_ptr(), n_res, 0, Xv.data_ptr(), n_ic, 0, n_bc, 0, 77, 5, st))
+    xr, xv = Xr.cpu().numpy(), Xv.cpu().numpy()
+    assert xr.min() >= 0.0 and xr.max() < 1.0 and abs(xr.mean() - 0.5) < 0.02
+    assert np.all(xv[:n_ic, 0] == 0.0) and np.all(xv[n_ic:, 1] == 0.0)            # IC: t = 0, BC1: x = 0
+    assert xv[:n_ic, 1:].std() > 0.2 and xv[n_ic:, [0, 2]].std() > 0.2
+    assert len(np.unique(xr[:, 0])) > 0.99 * n_res
+    # two "ranks" drawing their shards of the same global batch
+    h = n_res // 2
+    A = torch.empty(h, 3, device=gpu_device)
+    Bm = torch.empty(n_res - h, 3, device=gpu_device)
+    Va = torch.empty(700 + 600, 3, device=gpu_device)
+    L.check(lib.qc_sample_collocation(A.data_ptr(), h, 0, Va.data_ptr(), 700, 0, 600, 0, 77, 5, st))
+    L.check(lib.qc_sample_collocation(Bm.data_ptr(), n_res - h, h, Va.data_ptr(), 0, 0, 0, 0, 77, 5, st))
+    assert np.array_equal(np.concatenate([A.cpu().numpy(), Bm.cpu().numpy()]), xr)
+    assert np.array_equal(Va.cpu().numpy()[:700], xv[:700]) and np.array_equal(Va.cpu().numpy()[700:], xv[n_ic:n_ic + 600])
+    # another step -> different points
+    L.check(lib.qc_sample_collocation(Xr.data_ptr(), n_res, 0, Xv.data_ptr(), n_ic, 0, n_bc, 0, 77, 6, st))
+    assert not np.array_equal(Xr.cpu().numpy(), xr)
+
+
+def test_training_with_device_sampler_reduces_loss(gpu_device, tmp_path):
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    trainer = pkg("trainer.diffusion_train")
+    torch.manual_seed(1)
+    model = Solver(base_args(epochs=300, print_every=100), Log(tmp_path), device=gpu_device)
+    trainer.train(model, batch_size=8192)
+    h = np.array(model.loss_history)
+    assert h.shape == (301,) and np.all(np.isfinite(h))
+    assert h[-20:].mean() < 0.7 * h[:5].mean()
+    assert os.path.exists(os.path.join(str(tmp_path), "model.pth"))               # saved at print_every
