@@ -73,20 +73,24 @@ def time_kernels(tr, reps=20):
 
     calls = {
         "pre_fwd": lambda: lib.qc_pre_forward(d.X_res_dev, d.params_dev, d.H, d.n, d.n_theta, d.ajets_res_dev, d.B_res, 6, st),
-        "circuit_jets_fwd": lambda: lib.qc_forward_jets(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qjets_res_dev, d.B_res, st),
+        "circuit_jets_fwd": lambda: lib.qc_forward_jets(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qjets_res_dev, d.B_res, d.circ_ws_dev,
+                                                        d.circ_ws_bytes, st),
         "post": lambda: lib.qc_post(2, d.X_res_dev, d.params_dev, d.H, d.n, d.n_theta, pde, d.qjets_res_dev, d.abar_res_dev,
                                     d.abar_res_dev + 4 * d.B_res, None, None, d.qbar_res_dev, d.part_dev, d.part_stride, 0,
                                     d.B_res, 6, st),
         "circuit_jets_bwd": lambda: lib.qc_backward_jets(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qbar_res_dev,
-                                                         d.abar_res_dev, th, d.part_stride, 0, d.B_res, st),
+                                                         d.abar_res_dev, th, d.part_stride, 0, d.B_res, d.circ_ws_dev,
+                                                         d.circ_ws_bytes, st),
         "pre_bwd": lambda: lib.qc_pre_backward(d.X_res_dev, d.params_dev, d.H, d.n, d.n_theta, d.abar_res_dev, d.part_dev,
                                                d.part_stride, 0, d.B_res, 6, st),
         "value_pre_fwd": lambda: lib.qc_pre_forward(d.X_val_dev, d.params_dev, d.H, d.n, d.n_theta, d.ajets_val_dev, d.B_val, 1, st),
-        "value_circuit_fwd": lambda: lib.qc_forward_expval(d.prog, d.trig_dev, d.umat_dev, d.ajets_val_dev, d.qjets_val_dev, d.B_val, st),
+        "value_circuit_fwd": lambda: lib.qc_forward_expval(d.prog, d.trig_dev, d.umat_dev, d.ajets_val_dev, d.qjets_val_dev, d.B_val,
+                                                           d.circ_ws_dev, d.circ_ws_bytes, st),
         "value_post": lambda: lib.qc_post(2, d.X_val_dev, d.params_dev, d.H, d.n, d.n_theta, pde, d.qjets_val_dev, d.abar_val_dev,
                                           None, None, None, d.qbar_val_dev, d.part_dev, d.part_stride, rows_res, d.B_val, 1, st),
         "value_circuit_bwd": lambda: lib.qc_backward_expval(d.prog, d.trig_dev, d.umat_dev, d.ajets_val_dev, d.qbar_val_dev,
-                                                            d.abar_val_dev, th, d.part_stride, rows_res, d.B_val, st),
+                                                            d.abar_val_dev, th, d.part_stride, rows_res, d.B_val,
+                                                            d.circ_ws_dev, d.circ_ws_bytes, st),
         "value_pre_bwd": lambda: lib.qc_pre_backward(d.X_val_dev, d.params_dev, d.H, d.n, d.n_theta, d.abar_val_dev, d.part_dev,
                                                      d.part_stride, rows_res, d.B_val, 1, st),
         "reduce_rows": lambda: lib.qc_reduce_rows(d.part_dev, d.part_rows_cap, d.part_stride, eng.NP + 3, d.flat_dev, st),

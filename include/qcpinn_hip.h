@@ -46,23 +46,30 @@ size_t qc_trig_bytes(const qc_program* prog); /* size of the per-gate cos/sin wo
 /* cos/sin(theta/2) per gate; call after theta changes (the fused step does it itself). */
 int qc_prepare_gates(const qc_program* prog, const float* theta_dev, void* trig_dev, void* stream);
 
+/* Scratch the circuit entry points need for this program (0 for n <= 8: registers / lanes only;
+ * for 9 <= n <= 20 the statevectors of one 64-point tile live in HBM).  nch = 1 or 6. */
+size_t qc_circuit_workspace_bytes(const qc_program* prog, int nch, int backward);
+
 /* ---- DVQuantumLayer.forward, simulator batch branch (nn/DVQuantumLayer.py:151-154):
- * angles [n][B] -> <Z_w> [n][B].  umat_dev: [2 slots][fwd, adjoint][4x4 complex] floats or NULL. */
+ * angles [n][B] -> <Z_w> [n][B].  umat_dev: [2 slots][fwd, adjoint][4x4 complex] floats or NULL.
+ * ws_dev / ws_bytes: caller-owned scratch of at least qc_circuit_workspace_bytes() (may be NULL/0 if that is 0). */
 int qc_forward_expval(const qc_program* prog, const void* trig_dev, const float* umat_dev,
-                      const float* angles_dev, float* expval_dev, int64_t B, void* stream);
+                      const float* angles_dev, float* expval_dev, int64_t B, void* ws_dev, size_t ws_bytes,
+                      void* stream);
 /* its vector-Jacobian product (what loss.backward() asks of PennyLane's backprop):
  * cot [n][B] -> d_angles [n][B] and d_theta as partial rows at columns [0, n_params) of `part`. */
 int qc_backward_expval(const qc_program* prog, const void* trig_dev, const float* umat_dev,
                        const float* angles_dev, const float* cot_dev, float* d_angles_dev,
-                       float* part_dev, int64_t part_stride, int64_t row0, int64_t B, void* stream);
+                       float* part_dev, int64_t part_stride, int64_t row0, int64_t B, void* ws_dev, size_t ws_bytes,
+                       void* stream);
 
 /* ---- the same layer carrying the derivative channels that nn/pde.py:59-70 obtains with five
  * torch.autograd.grad(create_graph=True) calls through the simulator. */
 int qc_forward_jets(const qc_program* prog, const void* trig_dev, const float* umat_dev,
-                    const float* ajets_dev, float* qjets_dev, int64_t B, void* stream);
+                    const float* ajets_dev, float* qjets_dev, int64_t B, void* ws_dev, size_t ws_bytes, void* stream);
 int qc_backward_jets(const qc_program* prog, const void* trig_dev, const float* umat_dev,
                      const float* ajets_dev, const float* qbar_dev, float* abar_dev, float* part_dev,
-                     int64_t part_stride, int64_t row0, int64_t B, void* stream);
+                     int64_t part_stride, int64_t row0, int64_t B, void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ---- classical pre/post networks of DVPDESolver.forward (nn/DVPDESolver.py:37-51,81-110) with
  * the same channels.  nch = 6 (residual points) or 1 (boundary/initial points). */
@@ -138,6 +145,7 @@ typedef struct qc_step_desc {
   int64_t n_ic;                 /* leading IC points of the value batch (== pde.n_seg_a) */
   int64_t sample_off_res, sample_off_ic, sample_off_bc;
   uint64_t sample_seed, sample_step;
+  void* circ_ws_dev; size_t circ_ws_bytes;   /* >= qc_circuit_workspace_bytes(prog, 6, 1); NULL/0 when that is 0 */
 } qc_step_desc;
 
 #define QC_PHASE_GRADS 1

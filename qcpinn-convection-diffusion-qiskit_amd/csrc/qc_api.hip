@@ -35,6 +35,7 @@ static inline bool force_wave() {
 }
 static inline bool use_reg(int n) { return n >= 2 && n <= 5 && !force_wave(); }
 static inline bool use_wave(int n) { return n >= 1 && n <= 8; }
+static inline bool use_hbm(int n) { return n >= 9 && n <= 20; }
 
 extern "C" {
 
@@ -117,15 +118,24 @@ int qc_prepare_gates(const qc_program* p, const float* theta, void* trig, void* 
 static int check_circuit(const qc_program* p, const void* trig, const float* umat, int64_t B) {
   if (!p || !trig || B <= 0) return QC_ERR_ARG;
   if (p->n_u4 > 0 && !umat) return QC_ERR_ARG;
-  if (!use_reg(p->n_qubits) && !use_wave(p->n_qubits)) return QC_ERR_UNSUPPORTED;
+  if (!use_reg(p->n_qubits) && !use_wave(p->n_qubits) && !use_hbm(p->n_qubits)) return QC_ERR_UNSUPPORTED;
   return QC_OK;
 }
 
+size_t qc_circuit_workspace_bytes(const qc_program* p, int nch, int backward) {
+  if (!p || !use_hbm(p->n_qubits) || (nch != 1 && nch != 6)) return 0;
+  return qc_hbm_workspace_bytes(p, nch, backward != 0);
+}
+
 int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, const float* angles,
-                      float* expval, int64_t B, void* stream) {
+                      float* expval, int64_t B, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_circuit(p, trig, umat, B);
   if (rc) return rc;
   if (!angles || !expval) return QC_ERR_ARG;
+  if (use_hbm(p->n_qubits)) {
+    rc = qc_hbm_forward(p, (const QcTrig*)trig, umat, angles, expval, B, 1, ws, ws_bytes, (hipStream_t)stream);
+    return rc ? rc : after_launch();
+  }
   rc = use_reg(p->n_qubits)
            ? qc_reg_value_fwd(p, (const QcTrig*)trig, umat, angles, expval, B, (hipStream_t)stream)
            : qc_wave_value_fwd(p, (const QcTrig*)trig, umat, angles, expval, B, (hipStream_t)stream);
@@ -134,10 +144,15 @@ int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, 
 
 int qc_backward_expval(const qc_program* p, const void* trig, const float* umat, const float* angles,
                        const float* cot, float* d_angles, float* part, int64_t part_stride, int64_t row0,
-                       int64_t B, void* stream) {
+                       int64_t B, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_circuit(p, trig, umat, B);
   if (rc) return rc;
   if (!angles || !cot || !d_angles || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
+  if (use_hbm(p->n_qubits)) {
+    rc = qc_hbm_backward(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, 1, ws,
+                         ws_bytes, (hipStream_t)stream);
+    return rc ? rc : after_launch();
+  }
   rc = use_reg(p->n_qubits)
            ? qc_reg_value_bwd(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B,
                               (hipStream_t)stream)
@@ -147,10 +162,14 @@ int qc_backward_expval(const qc_program* p, const void* trig, const float* umat,
 }
 
 int qc_forward_jets(const qc_program* p, const void* trig, const float* umat, const float* ajets, float* qjets,
-                    int64_t B, void* stream) {
+                    int64_t B, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_circuit(p, trig, umat, B);
   if (rc) return rc;
   if (!ajets || !qjets) return QC_ERR_ARG;
+  if (use_hbm(p->n_qubits)) {
+    rc = qc_hbm_forward(p, (const QcTrig*)trig, umat, ajets, qjets, B, 6, ws, ws_bytes, (hipStream_t)stream);
+    return rc ? rc : after_launch();
+  }
   rc = use_reg(p->n_qubits)
            ? qc_reg_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, (hipStream_t)stream)
            : qc_wave_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, (hipStream_t)stream);
@@ -159,10 +178,15 @@ int qc_forward_jets(const qc_program* p, const void* trig, const float* umat, co
 
 int qc_backward_jets(const qc_program* p, const void* trig, const float* umat, const float* ajets,
                      const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
-                     void* stream) {
+                     void* ws, size_t ws_bytes, void* stream) {
   int rc = check_circuit(p, trig, umat, B);
   if (rc) return rc;
   if (!ajets || !qbar || !abar || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
+  if (use_hbm(p->n_qubits)) {
+    rc = qc_hbm_backward(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, 6, ws, ws_bytes,
+                         (hipStream_t)stream);
+    return rc ? rc : after_launch();
+  }
   rc = use_reg(p->n_qubits)
            ? qc_reg_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B,
                              (hipStream_t)stream)
@@ -259,13 +283,14 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (!d->X_res_dev || !d->ajets_res_dev || !d->qjets_res_dev || !d->qbar_res_dev || !d->abar_res_dev)
         return QC_ERR_ARG;
       if ((rc = qc_pre_forward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->ajets_res_dev, d->B_res, 6, st))) return rc;
-      if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, st))) return rc;
+      if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, d->circ_ws_dev,
+                                d->circ_ws_bytes, st))) return rc;
       // abar_res is written only by the adjoint sweep below: its head serves as cotangent scratch here
       if ((rc = qc_post(2, d->X_res_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_res_dev,
                         d->abar_res_dev, d->abar_res_dev + d->B_res, nullptr, nullptr, d->qbar_res_dev, d->part_dev,
                         d->part_stride, 0, d->B_res, 6, st))) return rc;
       if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
-                                 d->part_dev + L.oTh, d->part_stride, 0, d->B_res, st))) return rc;
+                                 d->part_dev + L.oTh, d->part_stride, 0, d->B_res, d->circ_ws_dev, d->circ_ws_bytes, st))) return rc;
       if ((rc = qc_pre_backward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->abar_res_dev, d->part_dev,
                                 d->part_stride, 0, d->B_res, 6, st))) return rc;
     }
@@ -273,12 +298,14 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (!d->X_val_dev || !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
         return QC_ERR_ARG;
       if ((rc = qc_pre_forward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->ajets_val_dev, d->B_val, 1, st))) return rc;
-      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qjets_val_dev, d->B_val, st))) return rc;
+      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qjets_val_dev, d->B_val, d->circ_ws_dev,
+                                  d->circ_ws_bytes, st))) return rc;
       if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev,
                         d->abar_val_dev, nullptr, nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride,
                         rows_res, d->B_val, 1, st))) return rc;
       if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev,
-                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, st))) return rc;
+                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, d->circ_ws_dev, d->circ_ws_bytes,
+                                   st))) return rc;
       if ((rc = qc_pre_backward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->abar_val_dev, d->part_dev,
                                 d->part_stride, rows_res, d->B_val, 1, st))) return rc;
     }

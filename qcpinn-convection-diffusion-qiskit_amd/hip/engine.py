@@ -80,6 +80,16 @@ class Circuit:
         except Exception:
             pass
 
+    # -- scratch for the HBM-resident family (n >= 9); empty for the register / lane families
+    def workspace(self, nch: int, backward: bool):
+        need = int(self.lib.qc_circuit_workspace_bytes(self.handle, nch, 1 if backward else 0))
+        if need == 0:
+            return None, 0
+        ws = getattr(self, "_ws", None)
+        if ws is None or ws.numel() < need:
+            self._ws = ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws.data_ptr(), ws.numel()
+
     # -- parameters changed: refresh cos/sin(theta/2)
     def prepare(self, theta: torch.Tensor) -> None:
         theta = _need(theta.reshape(-1), self.device, "theta")
@@ -90,8 +100,9 @@ class Circuit:
         a = _need(angles_nB, self.device, "angles")
         B = a.shape[1]
         out = torch.empty_like(a)
+        wp, wb = self.workspace(1, False)
         L.check(self.lib.qc_forward_expval(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
-                                           out.data_ptr(), B, _stream(self.device)), "qc_forward_expval")
+                                           out.data_ptr(), B, wp, wb, _stream(self.device)), "qc_forward_expval")
         return out
 
     def backward_expval(self, angles_nB: torch.Tensor, cot_nB: torch.Tensor):
@@ -103,8 +114,9 @@ class Circuit:
         part = torch.empty(rows, P, dtype=torch.float32, device=self.device)
         d_angles = torch.empty_like(a)
         st = _stream(self.device)
+        wp, wb = self.workspace(1, True)
         L.check(self.lib.qc_backward_expval(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
-                                            g.data_ptr(), d_angles.data_ptr(), part.data_ptr(), P, 0, B, st),
+                                            g.data_ptr(), d_angles.data_ptr(), part.data_ptr(), P, 0, B, wp, wb, st),
                 "qc_backward_expval")
         d_theta = torch.empty(P, dtype=torch.float32, device=self.device)
         L.check(self.lib.qc_reduce_rows(part.data_ptr(), rows, P, P, d_theta.data_ptr(), st), "qc_reduce_rows")
@@ -114,8 +126,9 @@ class Circuit:
         a = _need(ajets, self.device, "angle jets")            # (6, n, B)
         B = a.shape[2]
         out = torch.empty_like(a)
+        wp, wb = self.workspace(NCH, False)
         L.check(self.lib.qc_forward_jets(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
-                                         out.data_ptr(), B, _stream(self.device)), "qc_forward_jets")
+                                         out.data_ptr(), B, wp, wb, _stream(self.device)), "qc_forward_jets")
         return out
 
     def backward_jets(self, ajets: torch.Tensor, qbar: torch.Tensor):
@@ -127,8 +140,9 @@ class Circuit:
         part = torch.empty(rows, P, dtype=torch.float32, device=self.device)
         abar = torch.empty_like(a)
         st = _stream(self.device)
+        wp, wb = self.workspace(NCH, True)
         L.check(self.lib.qc_backward_jets(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
-                                          g.data_ptr(), abar.data_ptr(), part.data_ptr(), P, 0, B, st),
+                                          g.data_ptr(), abar.data_ptr(), part.data_ptr(), P, 0, B, wp, wb, st),
                 "qc_backward_jets")
         d_theta = torch.empty(P, dtype=torch.float32, device=self.device)
         L.check(self.lib.qc_reduce_rows(part.data_ptr(), rows, P, P, d_theta.data_ptr(), st), "qc_reduce_rows")
@@ -212,13 +226,14 @@ class SolverEngine:
         abar = torch.empty_like(ajets)
         th = part.data_ptr() + 4 * self.theta_off
         c = self.circuit
+        wp, wb = c.workspace(nch, True)
         if nch == 1:
             L.check(self.lib.qc_backward_expval(c.handle, c.trig.data_ptr(), _ptr(c.umat), ajets.data_ptr(),
-                                                qbar.data_ptr(), abar.data_ptr(), th, self.NP, 0, B, st),
+                                                qbar.data_ptr(), abar.data_ptr(), th, self.NP, 0, B, wp, wb, st),
                     "qc_backward_expval")
         else:
             L.check(self.lib.qc_backward_jets(c.handle, c.trig.data_ptr(), _ptr(c.umat), ajets.data_ptr(),
-                                              qbar.data_ptr(), abar.data_ptr(), th, self.NP, 0, B, st),
+                                              qbar.data_ptr(), abar.data_ptr(), th, self.NP, 0, B, wp, wb, st),
                     "qc_backward_jets")
         L.check(self.lib.qc_pre_backward(X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
                                          abar.data_ptr(), part.data_ptr(), self.NP, 0, B, nch, st),
@@ -314,6 +329,7 @@ class FusedStep:
         d.flat_dev = self.flat_grad.data_ptr()
         d.pde = eng._pde(max(g_res, 1), max(g_ic, 1), max(g_bc, 1), n_ic)
         d.hyper = opt.hyper
+        d.circ_ws_dev, d.circ_ws_bytes = c.workspace(NCH, True)
         d.n_ic = n_ic
         d.sample_off_res = d.sample_off_ic = d.sample_off_bc = 0
         d.sample_seed, d.sample_step = 0, 0

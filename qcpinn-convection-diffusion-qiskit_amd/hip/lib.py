@@ -20,7 +20,7 @@ QC_PHASE_SAMPLE = 4
 # every symbol include/qcpinn_hip.h declares
 EXPORTS = (
     "qc_version", "qc_error_string", "qc_last_hip_error", "qc_program_create", "qc_program_destroy",
-    "qc_trig_bytes", "qc_prepare_gates", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
+    "qc_trig_bytes", "qc_prepare_gates", "qc_circuit_workspace_bytes", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
     "qc_sample_collocation", "qc_fused_pinn_residual_step",
 )
@@ -60,6 +60,7 @@ class QcStepDesc(C.Structure):
         ("pde", QcPde), ("hyper", QcOptHyper),
         ("n_ic", C.c_int64), ("sample_off_res", C.c_int64), ("sample_off_ic", C.c_int64),
         ("sample_off_bc", C.c_int64), ("sample_seed", C.c_uint64), ("sample_step", C.c_uint64),
+        ("circ_ws_dev", C.c_void_p), ("circ_ws_bytes", C.c_size_t),
     ]
 
 
@@ -86,10 +87,12 @@ def load() -> C.CDLL:
     lib.qc_trig_bytes.restype = C.c_size_t
     lib.qc_trig_bytes.argtypes = [vp]
     lib.qc_prepare_gates.argtypes = [vp, fp, vp, vp]
-    lib.qc_forward_expval.argtypes = [vp, vp, fp, fp, fp, i64, vp]
-    lib.qc_backward_expval.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp]
-    lib.qc_forward_jets.argtypes = [vp, vp, fp, fp, fp, i64, vp]
-    lib.qc_backward_jets.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp]
+    lib.qc_circuit_workspace_bytes.restype = C.c_size_t
+    lib.qc_circuit_workspace_bytes.argtypes = [vp, i32, i32]
+    lib.qc_forward_expval.argtypes = [vp, vp, fp, fp, fp, i64, vp, C.c_size_t, vp]
+    lib.qc_backward_expval.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp, C.c_size_t, vp]
+    lib.qc_forward_jets.argtypes = [vp, vp, fp, fp, fp, i64, vp, C.c_size_t, vp]
+    lib.qc_backward_jets.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp, C.c_size_t, vp]
     lib.qc_pre_forward.argtypes = [fp, fp, i32, i32, i32, fp, i64, i32, vp]
     lib.qc_pre_backward.argtypes = [fp, fp, i32, i32, i32, fp, fp, i64, i64, i64, i32, vp]
     lib.qc_post.argtypes = [i32, fp, fp, i32, i32, i32, C.POINTER(QcPde), fp, fp, fp, fp, fp, fp, fp, i64, i64,
@@ -100,7 +103,7 @@ def load() -> C.CDLL:
     lib.qc_fused_pinn_residual_step.argtypes = [C.POINTER(QcStepDesc), i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("qc_error_string", "qc_trig_bytes"):
+        if name not in ("qc_error_string", "qc_trig_bytes", "qc_circuit_workspace_bytes"):
             fn.restype = i32
     _lib = lib
     return lib

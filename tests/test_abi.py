@@ -31,5 +31,5 @@ def test_argument_errors_do_not_need_a_gpu():
     lib = L.load()
     h = ctypes.c_void_p()
     assert lib.qc_program_create(None, 0, 4, 12, ctypes.byref(h)) == -1
-    assert lib.qc_forward_expval(None, None, None, None, None, 0, None) == -1
+    assert lib.qc_forward_expval(None, None, None, None, None, 0, None, 0, None) == -1
     assert lib.qc_reduce_rows(None, 0, 0, 0, None, None) == -1
