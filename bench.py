@@ -71,16 +71,22 @@ def time_kernels(tr, reps=20):
     pde = C.byref(d.pde)
     th = d.part_dev + 4 * NPo
 
+    keep = bool(d.circ_ws_dev) and 2 <= d.n <= 5    # the fused step's no-recompute adjoint pair
     calls = {
         "pre_fwd": lambda: lib.qc_pre_forward(d.X_res_dev, d.params_dev, d.H, d.n, d.n_theta, d.ajets_res_dev, d.B_res, 6, st),
-        "circuit_jets_fwd": lambda: lib.qc_forward_jets(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qjets_res_dev, d.B_res, d.circ_ws_dev,
-                                                        d.circ_ws_bytes, st),
+        "circuit_jets_fwd": (lambda: lib.qc_forward_jets_keep(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qjets_res_dev,
+                                                              d.B_res, d.circ_ws_dev, st)) if keep else
+                            (lambda: lib.qc_forward_jets(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qjets_res_dev, d.B_res,
+                                                         d.circ_ws_dev, d.circ_ws_bytes, st)),
         "post": lambda: lib.qc_post(2, d.X_res_dev, d.params_dev, d.H, d.n, d.n_theta, pde, d.qjets_res_dev, d.abar_res_dev,
                                     d.abar_res_dev + 4 * d.B_res, None, None, d.qbar_res_dev, d.part_dev, d.part_stride, 0,
                                     d.B_res, 6, st),
-        "circuit_jets_bwd": lambda: lib.qc_backward_jets(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qbar_res_dev,
-                                                         d.abar_res_dev, th, d.part_stride, 0, d.B_res, d.circ_ws_dev,
-                                                         d.circ_ws_bytes, st),
+        "circuit_jets_bwd": (lambda: lib.qc_backward_jets_kept(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qbar_res_dev,
+                                                               d.abar_res_dev, th, d.part_stride, 0, d.B_res, d.circ_ws_dev, st))
+                            if keep else
+                            (lambda: lib.qc_backward_jets(d.prog, d.trig_dev, d.umat_dev, d.ajets_res_dev, d.qbar_res_dev,
+                                                          d.abar_res_dev, th, d.part_stride, 0, d.B_res, d.circ_ws_dev,
+                                                          d.circ_ws_bytes, st)),
         "pre_bwd": lambda: lib.qc_pre_backward(d.X_res_dev, d.params_dev, d.H, d.n, d.n_theta, d.abar_res_dev, d.part_dev,
                                                d.part_stride, 0, d.B_res, 6, st),
         "value_pre_fwd": lambda: lib.qc_pre_forward(d.X_val_dev, d.params_dev, d.H, d.n, d.n_theta, d.ajets_val_dev, d.B_val, 1, st),

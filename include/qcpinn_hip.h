@@ -71,6 +71,15 @@ int qc_backward_jets(const qc_program* prog, const void* trig_dev, const float* 
                      const float* ajets_dev, const float* qbar_dev, float* abar_dev, float* part_dev,
                      int64_t part_stride, int64_t row0, int64_t B, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Register-family (2 <= n <= 5) pair that passes the forward pass's final statevectors to the adjoint
+ * pass through chi_dev [6][2*2^n][B] floats instead of recomputing them; both calls must see the same
+ * angle jets and parameters (the fused step uses them back to back). */
+int qc_forward_jets_keep(const qc_program* prog, const void* trig_dev, const float* umat_dev, const float* ajets_dev,
+                         float* qjets_dev, int64_t B, float* chi_dev, void* stream);
+int qc_backward_jets_kept(const qc_program* prog, const void* trig_dev, const float* umat_dev, const float* ajets_dev,
+                          const float* qbar_dev, float* abar_dev, float* part_dev, int64_t part_stride, int64_t row0,
+                          int64_t B, const float* chi_dev, void* stream);
+
 /* ---- classical pre/post networks of DVPDESolver.forward (nn/DVPDESolver.py:37-51,81-110) with
  * the same channels.  nch = 6 (residual points) or 1 (boundary/initial points). */
 int qc_pre_forward(const float* X_dev /*[B][3]*/, const float* params_dev, int H, int n, int n_theta,
@@ -145,8 +154,13 @@ typedef struct qc_step_desc {
   int64_t n_ic;                 /* leading IC points of the value batch (== pde.n_seg_a) */
   int64_t sample_off_res, sample_off_ic, sample_off_bc;
   uint64_t sample_seed, sample_step;
-  void* circ_ws_dev; size_t circ_ws_bytes;   /* >= qc_circuit_workspace_bytes(prog, 6, 1); NULL/0 when that is 0 */
+  void* circ_ws_dev; size_t circ_ws_bytes;   /* qc_step_workspace_bytes(prog, B_res); NULL/0 allowed when n <= 8 */
 } qc_step_desc;
+
+/* Scratch for one fused step on B_res residual points: the HBM statevector tile for n >= 9; for the
+ * register family (2 <= n <= 5) an optional [6][2*2^n][B_res] store of the forward pass's final states
+ * that lets the adjoint kernel skip recomputing them (pass less and it recomputes). */
+size_t qc_step_workspace_bytes(const qc_program* prog, int64_t B_res);
 
 #define QC_PHASE_GRADS 1
 #define QC_PHASE_UPDATE 2

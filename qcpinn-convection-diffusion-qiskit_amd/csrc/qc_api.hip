@@ -127,6 +127,13 @@ size_t qc_circuit_workspace_bytes(const qc_program* p, int nch, int backward) {
   return qc_hbm_workspace_bytes(p, nch, backward != 0);
 }
 
+size_t qc_step_workspace_bytes(const qc_program* p, int64_t B_res) {
+  if (!p || B_res < 0) return 0;
+  if (use_hbm(p->n_qubits)) return qc_hbm_workspace_bytes(p, 6, true);
+  if (use_reg(p->n_qubits)) return qc_reg_chi_store_bytes(p, B_res);   // optional: enables the no-recompute adjoint
+  return 0;
+}
+
 int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, const float* angles,
                       float* expval, int64_t B, void* ws, size_t ws_bytes, void* stream) {
   int rc = check_circuit(p, trig, umat, B);
@@ -171,7 +178,7 @@ int qc_forward_jets(const qc_program* p, const void* trig, const float* umat, co
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
-           ? qc_reg_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, (hipStream_t)stream)
+           ? qc_reg_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, nullptr, (hipStream_t)stream)
            : qc_wave_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, (hipStream_t)stream);
   return rc ? rc : after_launch();
 }
@@ -188,10 +195,34 @@ int qc_backward_jets(const qc_program* p, const void* trig, const float* umat, c
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
-           ? qc_reg_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B,
+           ? qc_reg_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, nullptr,
                              (hipStream_t)stream)
            : qc_wave_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B,
                               (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+// Register-family variants that hand the forward pass's final states to the adjoint pass through
+// chi_dev [6][2*2^n][B] instead of recomputing them (12 instead of 18 circuit-equivalents per point).
+int qc_forward_jets_keep(const qc_program* p, const void* trig, const float* umat, const float* ajets, float* qjets,
+                         int64_t B, float* chi, void* stream) {
+  int rc = check_circuit(p, trig, umat, B);
+  if (rc) return rc;
+  if (!ajets || !qjets || !chi) return QC_ERR_ARG;
+  if (!use_reg(p->n_qubits)) return QC_ERR_UNSUPPORTED;
+  rc = qc_reg_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, chi, (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
+int qc_backward_jets_kept(const qc_program* p, const void* trig, const float* umat, const float* ajets,
+                          const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
+                          const float* chi, void* stream) {
+  int rc = check_circuit(p, trig, umat, B);
+  if (rc) return rc;
+  if (!ajets || !qbar || !abar || !part || !chi || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
+  if (!use_reg(p->n_qubits)) return QC_ERR_UNSUPPORTED;
+  rc = qc_reg_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, chi,
+                       (hipStream_t)stream);
   return rc ? rc : after_launch();
 }
 
@@ -283,14 +314,26 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (!d->X_res_dev || !d->ajets_res_dev || !d->qjets_res_dev || !d->qbar_res_dev || !d->abar_res_dev)
         return QC_ERR_ARG;
       if ((rc = qc_pre_forward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->ajets_res_dev, d->B_res, 6, st))) return rc;
-      if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, d->circ_ws_dev,
-                                d->circ_ws_bytes, st))) return rc;
+      // register family: keep the final states of the forward pass for the adjoint kernel of this step
+      float* chi_store = (use_reg(n) && d->circ_ws_dev && d->circ_ws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res))
+                             ? (float*)d->circ_ws_dev : nullptr;
+      if (use_reg(n)) {
+        if ((rc = qc_reg_jets_fwd(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, chi_store, st)))
+          return rc;
+        if ((rc = after_launch())) return rc;
+      } else if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res,
+                                       d->circ_ws_dev, d->circ_ws_bytes, st))) return rc;
       // abar_res is written only by the adjoint sweep below: its head serves as cotangent scratch here
       if ((rc = qc_post(2, d->X_res_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_res_dev,
                         d->abar_res_dev, d->abar_res_dev + d->B_res, nullptr, nullptr, d->qbar_res_dev, d->part_dev,
                         d->part_stride, 0, d->B_res, 6, st))) return rc;
-      if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
-                                 d->part_dev + L.oTh, d->part_stride, 0, d->B_res, d->circ_ws_dev, d->circ_ws_bytes, st))) return rc;
+      if (use_reg(n)) {
+        if ((rc = qc_reg_jets_bwd(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
+                                  d->part_dev + L.oTh, d->part_stride, 0, d->B_res, chi_store, st))) return rc;
+        if ((rc = after_launch())) return rc;
+      } else if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
+                                        d->part_dev + L.oTh, d->part_stride, 0, d->B_res, d->circ_ws_dev,
+                                        d->circ_ws_bytes, st))) return rc;
       if ((rc = qc_pre_backward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->abar_res_dev, d->part_dev,
                                 d->part_stride, 0, d->B_res, 6, st))) return rc;
     }

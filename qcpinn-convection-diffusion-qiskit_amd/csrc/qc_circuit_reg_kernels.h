@@ -286,7 +286,7 @@ template <class PG>
 __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates,
                                                   const float* __restrict__ ajets, float* __restrict__ qjets,
-                                                  int64_t B) {
+                                                  int64_t B, float* __restrict__ chi_store) {
   constexpr int N = PG::N;
   constexpr int A2 = 2 << N;                 // floats per statevector
   __shared__ float s_chi0[A2 * 64];          // [amp*2+{re,im}][lane]
@@ -299,6 +299,13 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
   SV<N> v[1];
   build_channel<N>(v[0], ch, ajets, B, pc);
   PG::fwd(v, prog, trig, umat, n_gates);
+  if (chi_store != nullptr && p < B) {   // final states for the adjoint kernel of the same step: [6][A2][B]
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      chi_store[((int64_t)ch * A2 + 2 * k) * B + p] = v[0].re[k];
+      chi_store[((int64_t)ch * A2 + 2 * k + 1) * B + p] = v[0].im[k];
+    }
+  }
 
   float t[1 << N], q[N];
   if (ch == 0) {
@@ -338,12 +345,15 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
 #ifndef QC_JB_WAVES
 #define QC_JB_WAVES 3
 #endif
-template <class PG>
+// LOAD: the final states come from chi_store (written by k_jets_fwd in the same step) instead of being
+// recomputed from the angle jets: 12 instead of 18 circuit-equivalents per point.
+template <class PG, bool LOAD>
 __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates, int n_params,
                                                   const float* __restrict__ ajets, const float* __restrict__ qbar,
                                                   float* __restrict__ abar, float* __restrict__ part,
-                                                  int64_t part_stride, int64_t row0, int64_t B) {
+                                                  int64_t part_stride, int64_t row0, int64_t B,
+                                                  const float* __restrict__ chi_store) {
   constexpr int N = PG::N;
   constexpr int A2 = 2 << N;
   extern __shared__ float smem[];
@@ -358,7 +368,13 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
   const int64_t pc = live ? p : B - 1;
 
   SV<N> cl[2];
-  {
+  if constexpr (LOAD) {
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      cl[0].re[k] = chi_store[((int64_t)ch * A2 + 2 * k) * B + pc];
+      cl[0].im[k] = chi_store[((int64_t)ch * A2 + 2 * k + 1) * B + pc];
+    }
+  } else {
     SV<N> v[1];
     build_channel<N>(v[0], ch, ajets, B, pc);
     PG::fwd(v, prog, trig, umat, n_gates);
@@ -481,9 +497,9 @@ struct QcRegLaunchers {
   int (*value_fwd)(const qc_program*, const QcTrig*, const float*, const float*, float*, int64_t, hipStream_t);
   int (*value_bwd)(const qc_program*, const QcTrig*, const float*, const float*, const float*, float*, float*,
                    int64_t, int64_t, int64_t, hipStream_t);
-  int (*jets_fwd)(const qc_program*, const QcTrig*, const float*, const float*, float*, int64_t, hipStream_t);
+  int (*jets_fwd)(const qc_program*, const QcTrig*, const float*, const float*, float*, int64_t, float*, hipStream_t);
   int (*jets_bwd)(const qc_program*, const QcTrig*, const float*, const float*, const float*, float*, float*,
-                  int64_t, int64_t, int64_t, hipStream_t);
+                  int64_t, int64_t, int64_t, const float*, hipStream_t);
 };
 
 template <class PG>
@@ -503,24 +519,30 @@ struct RegLaunch {
     return QC_OK;
   }
   static int jets_fwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
-                      float* qjets, int64_t B, hipStream_t st) {
+                      float* qjets, int64_t B, float* chi_store, hipStream_t st) {
     hipLaunchKernelGGL(k_jets_fwd<PG>, dim3(qc_ceil_div(B, 64)), dim3(384), 0, st, pg->d_gates, trig, umat,
-                       pg->n_gates, ajets, qjets, B);
+                       pg->n_gates, ajets, qjets, B, chi_store);
     return QC_OK;
   }
   static int jets_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
                       const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
-                      hipStream_t st) {
+                      const float* chi_store, hipStream_t st) {
     const size_t sh = ((size_t)6 * (2u << PG::N) * 64 + (size_t)6 * pg->n_params) * sizeof(float);
     if (sh > 160 * 1024) return QC_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jets_bwd<PG>),
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jets_bwd<PG, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_jets_bwd<PG, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(k_jets_bwd<PG>, dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
-                       pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B);
+    if (chi_store != nullptr)
+      hipLaunchKernelGGL((k_jets_bwd<PG, true>), dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
+                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store);
+    else
+      hipLaunchKernelGGL((k_jets_bwd<PG, false>), dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
+                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store);
     return QC_OK;
   }
   static constexpr QcRegLaunchers table() { return {&value_fwd, &value_bwd, &jets_fwd, &jets_bwd}; }

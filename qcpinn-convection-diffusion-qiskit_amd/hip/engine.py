@@ -329,7 +329,9 @@ class FusedStep:
         d.flat_dev = self.flat_grad.data_ptr()
         d.pde = eng._pde(max(g_res, 1), max(g_ic, 1), max(g_bc, 1), n_ic)
         d.hyper = opt.hyper
-        d.circ_ws_dev, d.circ_ws_bytes = c.workspace(NCH, True)
+        need = int(eng.lib.qc_step_workspace_bytes(c.handle, B_res))
+        self.step_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        d.circ_ws_dev, d.circ_ws_bytes = (self.step_ws.data_ptr(), need) if need else (None, 0)
         d.n_ic = n_ic
         d.sample_off_res = d.sample_off_ic = d.sample_off_bc = 0
         d.sample_seed, d.sample_step = 0, 0

@@ -21,8 +21,8 @@ QC_PHASE_SAMPLE = 4
 EXPORTS = (
     "qc_version", "qc_error_string", "qc_last_hip_error", "qc_program_create", "qc_program_destroy",
     "qc_trig_bytes", "qc_prepare_gates", "qc_circuit_workspace_bytes", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
-    "qc_backward_jets", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
-    "qc_sample_collocation", "qc_fused_pinn_residual_step",
+    "qc_backward_jets", "qc_forward_jets_keep", "qc_backward_jets_kept", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
+    "qc_sample_collocation", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
 )
 
 
@@ -93,6 +93,8 @@ def load() -> C.CDLL:
     lib.qc_backward_expval.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp, C.c_size_t, vp]
     lib.qc_forward_jets.argtypes = [vp, vp, fp, fp, fp, i64, vp, C.c_size_t, vp]
     lib.qc_backward_jets.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp, C.c_size_t, vp]
+    lib.qc_forward_jets_keep.argtypes = [vp, vp, fp, fp, fp, i64, fp, vp]
+    lib.qc_backward_jets_kept.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, fp, vp]
     lib.qc_pre_forward.argtypes = [fp, fp, i32, i32, i32, fp, i64, i32, vp]
     lib.qc_pre_backward.argtypes = [fp, fp, i32, i32, i32, fp, fp, i64, i64, i64, i32, vp]
     lib.qc_post.argtypes = [i32, fp, fp, i32, i32, i32, C.POINTER(QcPde), fp, fp, fp, fp, fp, fp, fp, i64, i64,
@@ -100,10 +102,12 @@ def load() -> C.CDLL:
     lib.qc_reduce_rows.argtypes = [fp, i64, i64, i32, fp, vp]
     lib.qc_adam_step.argtypes = [fp, i32, fp, fp, fp, vp, C.POINTER(QcOptHyper), fp, i32, vp, i32, vp, vp]
     lib.qc_sample_collocation.argtypes = [fp, i64, i64, fp, i64, i64, i64, i64, C.c_uint64, C.c_uint64, vp]
+    lib.qc_step_workspace_bytes.restype = C.c_size_t
+    lib.qc_step_workspace_bytes.argtypes = [vp, i64]
     lib.qc_fused_pinn_residual_step.argtypes = [C.POINTER(QcStepDesc), i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("qc_error_string", "qc_trig_bytes", "qc_circuit_workspace_bytes"):
+        if name not in ("qc_error_string", "qc_trig_bytes", "qc_circuit_workspace_bytes", "qc_step_workspace_bytes"):
             fn.restype = i32
     _lib = lib
     return lib

@@ -167,6 +167,13 @@ def make_train(tag, args, batch_size):
              batch_size=np.array(batch_size), **init, **final)
 
 
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "n16":
+    # the 16-qubit cross_mesh model of BASELINE config 5 (2 221 parameters), tiny batches
+    a16 = base_args(num_qubits=16, q_ansatz="cross_mesh")
+    make_operator("cross_mesh_n16", a16, 2)
+    make_train("cross_mesh_n16_b6", dict(a16, epochs=1), 6)
+    sys.exit(0)
+
 if __name__ == "__main__":
     make_analytic()
     make_haar()

@@ -44,7 +44,8 @@ def flat_grad(model):
 
 
 OPERATOR_CASES = [("cascade_n4", {}), ("cross_mesh_n4", {"q_ansatz": "cross_mesh"}),
-                  ("layered_n8", {"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"})]
+                  ("layered_n8", {"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"}),
+                  ("cross_mesh_n16", {"num_qubits": 16, "q_ansatz": "cross_mesh"})]
 
 
 @pytest.mark.parametrize("tag,over", OPERATOR_CASES)
@@ -201,3 +202,38 @@ def test_training_with_device_sampler_reduces_loss(gpu_device, tmp_path):
     assert h.shape == (301,) and np.all(np.isfinite(h))
     assert h[-20:].mean() < 0.7 * h[:5].mean()
     assert os.path.exists(os.path.join(str(tmp_path), "model.pth"))               # saved at print_every
+
+
+def test_grid_evaluation_and_checkpoint_roundtrip(gpu_device, tmp_path):
+    """20^3-grid inference of (u, residual) + relative L2 errors, and a checkpoint
+    written by save_state reloads into a fresh model that evaluates identically."""
+    from oracle import solver as osol
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    ev = pkg("trainer.evaluate")
+    z = np.load(os.path.join(GOLDEN, "train_cascade_n4_b64.npz"))
+    torch.manual_seed(3)
+    model = Solver(base_args(), Log(tmp_path), device=gpu_device)
+    load_weights(model, z, "w1__")
+    out = ev.evaluate(model, 20)
+    assert out["u_pred"].shape == (20, 20, 20) and np.isfinite(out["error_u"]) and np.isfinite(out["error_f"])
+    # same numbers from the oracle model (reference algorithm) on the same weights
+    torch.manual_seed(3)
+    om = osol.OracleSolver(base_args())
+    load_weights(om, z, "w1__")
+    X = torch.from_numpy(out["X"])
+    idx = torch.arange(0, 8000, 97)
+    Xs = X[idx]
+    u_o, f_o = osol.diffusion_residual(om, Xs[:, 0:1].clone(), Xs[:, 1:2].clone(), Xs[:, 2:3].clone())
+    assert np.abs(u_o.detach().numpy()[:, 0] - out["u_pred"].reshape(-1)[idx.numpy()]).max() < 2e-5
+    fs = max(1.0, float(f_o.abs().max()))
+    assert np.abs(f_o.detach().numpy()[:, 0] - out["f_pred"].reshape(-1)[idx.numpy()]).max() < 1e-4 * fs
+    # checkpoint interchange: same keys, reload into a new model
+    path = os.path.join(str(tmp_path), "ck.pth")
+    model.save_state(path)
+    st = Solver.load_state(path)
+    m2 = Solver(base_args(), Log(tmp_path), device=gpu_device)
+    m2.preprocessor.load_state_dict(st["preprocessor"])
+    m2.postprocessor.load_state_dict(st["postprocessor"])
+    m2.quantum_layer.load_state_dict(st["quantum_layer"])
+    out2 = ev.evaluate(m2, 20)
+    assert out2["error_u"] == out["error_u"] and out2["error_f"] == out["error_f"]
