@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 static_assert(sizeof(QcPde) == sizeof(qc_pde), "qc_pde layout");
 static_assert(sizeof(QcOptHyper) == sizeof(qc_opt_hyper), "qc_opt_hyper layout");
 
@@ -36,6 +38,31 @@ static inline bool force_wave() {
 static inline bool use_reg(int n) { return n >= 2 && n <= 5 && !force_wave(); }
 static inline bool use_wave(int n) { return n >= 1 && n <= 8; }
 static inline bool use_hbm(int n) { return n >= 9 && n <= 20; }
+
+// A side stream per device so the (small) boundary/initial-value pipeline of a step can overlap the
+// residual pipeline; created once, on first use, never inside a graph capture of the caller.
+struct QcSide {
+  hipStream_t s = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false, tried = false;
+};
+static QcSide* side_stream() {
+  static QcSide tab[64];
+  static std::mutex mu;
+  static const bool off = [] { const char* e = getenv("QC_NO_OVERLAP"); return e && e[0] == '1'; }();
+  if (off) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  QcSide& q = tab[dev];
+  if (!q.tried) {
+    q.tried = true;
+    q.ok = hipStreamCreateWithFlags(&q.s, hipStreamNonBlocking) == hipSuccess &&
+           hipEventCreateWithFlags(&q.fork, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&q.join, hipEventDisableTiming) == hipSuccess;
+  }
+  return q.ok ? &q : nullptr;
+}
 
 extern "C" {
 
@@ -310,6 +337,31 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
                                     d->sample_step, st))) return rc;
   }
   if (phases & QC_PHASE_GRADS) {
+    // the two pipelines are independent until the row reduction: fork the value pipeline onto a side
+    // stream (not for n >= 9, where both would share the HBM statevector workspace)
+    QcSide* side = (d->B_res > 0 && d->B_val > 0 && !use_hbm(n)) ? side_stream() : nullptr;
+    hipStream_t sv = st;
+    if (side) {
+      if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
+        side = nullptr;
+      else
+        sv = side->s;
+    }
+    if (d->B_val > 0) {
+      if (!d->X_val_dev || !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
+        return QC_ERR_ARG;
+      if ((rc = qc_pre_forward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->ajets_val_dev, d->B_val, 1, sv))) return rc;
+      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qjets_val_dev, d->B_val, d->circ_ws_dev,
+                                  d->circ_ws_bytes, sv))) return rc;
+      if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev,
+                        d->abar_val_dev, nullptr, nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride,
+                        rows_res, d->B_val, 1, sv))) return rc;
+      if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev,
+                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, d->circ_ws_dev, d->circ_ws_bytes,
+                                   sv))) return rc;
+      if ((rc = qc_pre_backward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->abar_val_dev, d->part_dev,
+                                d->part_stride, rows_res, d->B_val, 1, sv))) return rc;
+    }
     if (d->B_res > 0) {
       if (!d->X_res_dev || !d->ajets_res_dev || !d->qjets_res_dev || !d->qbar_res_dev || !d->abar_res_dev)
         return QC_ERR_ARG;
@@ -337,20 +389,10 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if ((rc = qc_pre_backward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->abar_res_dev, d->part_dev,
                                 d->part_stride, 0, d->B_res, 6, st))) return rc;
     }
-    if (d->B_val > 0) {
-      if (!d->X_val_dev || !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
-        return QC_ERR_ARG;
-      if ((rc = qc_pre_forward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->ajets_val_dev, d->B_val, 1, st))) return rc;
-      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qjets_val_dev, d->B_val, d->circ_ws_dev,
-                                  d->circ_ws_bytes, st))) return rc;
-      if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev,
-                        d->abar_val_dev, nullptr, nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride,
-                        rows_res, d->B_val, 1, st))) return rc;
-      if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev,
-                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, d->circ_ws_dev, d->circ_ws_bytes,
-                                   st))) return rc;
-      if ((rc = qc_pre_backward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->abar_val_dev, d->part_dev,
-                                d->part_stride, rows_res, d->B_val, 1, st))) return rc;
+    if (side) {
+      hipError_t e = hipEventRecord(side->join, sv);
+      if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);
+      if (e != hipSuccess) return hip_fail(e);
     }
     if ((rc = qc_reduce_rows(d->part_dev, rows, d->part_stride, L.NP + 3, d->flat_dev, st))) return rc;
   }
