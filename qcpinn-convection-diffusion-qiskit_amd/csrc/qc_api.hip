@@ -1,6 +1,7 @@
 // extern "C" entry points of libqcpinn_hip.so (declared in include/qcpinn_hip.h).
 // Argument checking happens here, once, on the host: the kernels assume validated shapes.
 #include "qc_internal.h"
+#include "qc_hbm_plan.h"
 #include "../../include/qcpinn_hip.h"
 
 #include <stdlib.h>
@@ -114,6 +115,7 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   p->n_qubits = n_qubits; p->n_gates = n_gates; p->n_params = n_params; p->n_u4 = n_u4;
   p->h_gates = h; p->d_gates = nullptr;
   p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p) : -1;
+  p->hbm_plan = nullptr;
   hipError_t e = hipMalloc((void**)&p->d_gates, sizeof(QcGate) * n_gates);
   if (e == hipSuccess) e = hipMemcpy(p->d_gates, h, sizeof(QcGate) * n_gates, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -122,12 +124,22 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
     free(p);
     return hip_fail(e);
   }
+  if (n_qubits >= 9 && n_qubits <= 20) {
+    p->hbm_plan = qc_hbm_plan_create(p);
+    if (!p->hbm_plan) {
+      (void)hipFree(p->d_gates);
+      free(h);
+      free(p);
+      return QC_ERR_ALLOC;
+    }
+  }
   *out = p;
   return QC_OK;
 }
 
 int qc_program_destroy(qc_program* p) {
   if (!p) return QC_ERR_ARG;
+  if (p->hbm_plan) qc_hbm_plan_destroy((QcHbmPlan*)p->hbm_plan);
   if (p->d_gates) (void)hipFree(p->d_gates);
   free(p->h_gates);
   free(p);

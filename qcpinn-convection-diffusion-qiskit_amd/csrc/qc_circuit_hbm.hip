@@ -15,6 +15,13 @@
 //   gblk [blocks]    float      per-block gradient partials of the current gate
 // One 64-point tile at a time, so every tile owns one gradient partial row like the other families.
 #include "qc_internal.h"
+#include "qc_hbm_plan.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -347,6 +354,221 @@ __global__ void k_hbm_store_row(const float* __restrict__ acc, int n_params, flo
   if (i < n_params) row[i] = acc[i];
 }
 
+
+// ================================================================== staged execution (qc_hbm_plan.h)
+__device__ __forceinline__ int64_t dep_local(int l, const QcStage& sd, int l0) {
+  int64_t a = l & ((1 << l0) - 1);
+  for (int j = l0; j < sd.nloc; ++j)
+    if ((l >> j) & 1) a |= (int64_t)1 << sd.lb[j];
+  return a;
+}
+__device__ __forceinline__ int64_t dep_global(int tau, const QcStage& sd) {
+  int64_t a = 0;
+  for (int j = 0; j < sd.ngb; ++j)
+    if ((tau >> j) & 1) a |= (int64_t)1 << sd.gb[j];
+  return a;
+}
+__device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Cplx cmulc(Cplx a, Cplx b) { return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }  // a * conj(b)
+
+// block-wide sum (256 threads); result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* s_red) {
+  const float w = qc_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// One L stage on one tile of one statevector (GRAD: of the chi/lam pair v, v + nvec).
+// grid = nvec * 2^ngb blocks.  Forward: gates in order, then the fused diagonal table at the store.
+// ADJ: the table's conjugate at the load, then the adjoint gates in reverse order; GRAD additionally
+// writes, per parametric gate, this block's partial of Im<lam|G|chi> to gpart[gate][block].
+template <bool ADJ, bool GRAD>
+__global__ void __launch_bounds__(256) k_hbm_stage(Cplx* __restrict__ st, int64_t nvec, int n, QcStage sd,
+                                                   const QcStageGate* __restrict__ gl, const QcTrig* __restrict__ trig,
+                                                   const float* __restrict__ umat, const Cplx* __restrict__ tab,
+                                                   float* __restrict__ gpart) {
+  extern __shared__ Cplx tile[];        // [GRAD ? 2 : 1][2^nloc]
+  __shared__ float s_red[4];
+  const int64_t N = (int64_t)1 << n;
+  const int TS = 1 << sd.nloc;
+  const int l0 = sd.nloc < QC_HBM_L0 ? sd.nloc : QC_HBM_L0;
+  const int tiles = 1 << sd.ngb;
+  const int64_t v = blockIdx.x / tiles;
+  const int tau = blockIdx.x % tiles;
+  const int64_t base = dep_global(tau, sd);
+  Cplx* t0 = tile;
+  Cplx* t1 = tile + TS;
+  Cplx* g0 = st + v * N;
+  Cplx* g1 = st + (v + nvec) * N;
+  for (int l = threadIdx.x; l < TS; l += 256) {
+    const int64_t a = base | dep_local(l, sd, l0);
+    Cplx x = g0[a];
+    if (ADJ && tab != nullptr) x = cmulc(x, tab[a]);
+    t0[l] = x;
+    if constexpr (GRAD) {
+      Cplx y = g1[a];
+      if (ADJ && tab != nullptr) y = cmulc(y, tab[a]);
+      t1[l] = y;
+    }
+  }
+  __syncthreads();
+  int pidx = 0;  // running index of parametric gates in this stage (execution order)
+  for (int i = 0; i < sd.ng; ++i) {
+    const QcStageGate g = gl[sd.g0 + (ADJ ? sd.ng - 1 - i : i)];
+    if (g.op == QC_U4) {
+      const float* u = umat + (g.slot * 2 + (ADJ ? 1 : 0)) * 32;
+      const int lo = g.jt < g.jc ? g.jt : g.jc, hi = g.jt < g.jc ? g.jc : g.jt;
+      for (int q = threadIdx.x; q < (TS >> 2); q += 256) {
+        int b = ((q >> lo) << (lo + 1)) | (q & ((1 << lo) - 1));
+        b = ((b >> hi) << (hi + 1)) | (b & ((1 << hi) - 1));
+        const int idx[4] = {b, b | (1 << g.jc), b | (1 << g.jt), b | (1 << g.jt) | (1 << g.jc)};
+#pragma unroll
+        for (int w = 0; w < (GRAD ? 2 : 1); ++w) {
+          Cplx* t = w == 0 ? t0 : t1;
+          Cplx x[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x[k] = t[idx[k]];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float yr = 0.f, yi = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float ur = u[(r * 4 + k) * 2], ui = u[(r * 4 + k) * 2 + 1];
+              yr += ur * x[k].re - ui * x[k].im;
+              yi += ur * x[k].im + ui * x[k].re;
+            }
+            t[idx[r]] = {yr, yi};
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    const QcTrig tr = trig[g.gi];
+    const float c = tr.c, s = ADJ ? -tr.s : tr.s;
+    float a0r, a0i, b0r, b0i, a1r, a1i, b1r, b1i;
+    coef_of(g.op, c, s, false, a0r, a0i, b0r, b0i);
+    coef_of(g.op, c, s, true, a1r, a1i, b1r, b1i);
+    float grad = 0.f;
+    for (int p = threadIdx.x; p < (TS >> 1); p += 256) {
+      const int i0 = ((p >> g.jt) << (g.jt + 1)) | (p & ((1 << g.jt) - 1));
+      const int i1 = i0 | (1 << g.jt);
+      if (g.jc >= 0 && !((i0 >> g.jc) & 1)) continue;
+      const Cplx x0 = t0[i0], x1 = t0[i1];
+      if constexpr (GRAD) {
+        const Cplx q0 = t1[i0], q1 = t1[i1];
+        switch (g.op) {
+          case QC_RX: case QC_CRX:
+            grad += (q0.re * x1.im - q0.im * x1.re) + (q1.re * x0.im - q1.im * x0.re);
+            break;
+          case QC_RY:
+            grad += -(q0.re * x1.re + q0.im * x1.im) + (q1.re * x0.re + q1.im * x0.im);
+            break;
+          case QC_RZ: case QC_CRZ:
+            grad += (q0.re * x0.im - q0.im * x0.re) - (q1.re * x1.im - q1.im * x1.re);
+            break;
+          default: break;
+        }
+        t1[i0] = {a0r * q0.re - a0i * q0.im + b0r * q1.re - b0i * q1.im, a0r * q0.im + a0i * q0.re + b0r * q1.im + b0i * q1.re};
+        t1[i1] = {a1r * q1.re - a1i * q1.im + b1r * q0.re - b1i * q0.im, a1r * q1.im + a1i * q1.re + b1r * q0.im + b1i * q0.re};
+      }
+      t0[i0] = {a0r * x0.re - a0i * x0.im + b0r * x1.re - b0i * x1.im, a0r * x0.im + a0i * x0.re + b0r * x1.im + b0i * x1.re};
+      t0[i1] = {a1r * x1.re - a1i * x1.im + b1r * x0.re - b1i * x0.im, a1r * x1.im + a1i * x1.re + b1r * x0.im + b1i * x0.re};
+    }
+    if constexpr (GRAD) {
+      if (g.slot >= 0) {
+        const float tot = block_sum_256(grad, s_red);
+        if (threadIdx.x == 0) gpart[(size_t)pidx * gridDim.x + blockIdx.x] = tot;
+        ++pidx;
+      }
+    }
+    __syncthreads();
+  }
+  for (int l = threadIdx.x; l < TS; l += 256) {
+    const int64_t a = base | dep_local(l, sd, l0);
+    Cplx x = t0[l];
+    if (!ADJ && tab != nullptr) x = cmul(x, tab[a]);
+    g0[a] = x;
+    if constexpr (GRAD) {
+      Cplx y = t1[l];
+      if (!ADJ && tab != nullptr) y = cmul(y, tab[a]);
+      g1[a] = y;
+    }
+  }
+}
+
+// acc[slot_i] += sum_b gpart[i][b] for the parametric gates of one stage, in execution order
+__global__ void __launch_bounds__(256) k_hbm_fold_stage(const float* __restrict__ gpart, int nblk,
+                                                        const int* __restrict__ slots, float* __restrict__ acc) {
+  __shared__ float s_red[4];
+  const int i = blockIdx.x;
+  float t = 0.f;
+  for (int b = threadIdx.x; b < nblk; b += 256) t += gpart[(size_t)i * nblk + b];
+  const float tot = block_sum_256(t, s_red);
+  if (threadIdx.x == 0) acc[slots[i]] += tot;
+}
+
+// phase table of one diagonal run: tab[k] = prod_g phase_g(k), accumulated in double
+__global__ void __launch_bounds__(256) k_hbm_diag_table(const QcDiagGate* __restrict__ dg, int ng,
+                                                        const QcTrig* __restrict__ trig, int n, Cplx* __restrict__ tab) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= ((int64_t)1 << n)) return;
+  double zr = 1.0, zi = 0.0;
+  for (int i = 0; i < ng; ++i) {
+    const QcDiagGate g = dg[i];
+    if (g.bc >= 0 && !((k >> g.bc) & 1)) continue;
+    const QcTrig tr = trig[g.gi];
+    const double c = tr.c, s = ((k >> g.bt) & 1) ? (double)tr.s : -(double)tr.s;   // bit 0: c - i s, bit 1: c + i s
+    const double nr = zr * c - zi * s, ni = zr * s + zi * c;
+    zr = nr;
+    zi = ni;
+  }
+  tab[k] = {(float)zr, (float)zi};
+}
+
+template <bool ADJ>
+__global__ void __launch_bounds__(256) k_hbm_diag_apply(Cplx* __restrict__ st, int64_t S, int n, const Cplx* __restrict__ tab) {
+  const int64_t N = (int64_t)1 << n;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= S * N) return;
+  const int64_t k = gid & (N - 1);
+  st[gid] = ADJ ? cmulc(st[gid], tab[k]) : cmul(st[gid], tab[k]);
+}
+
+// W partials: wp[grp][k] = sum over this group's (chi, lam) pairs of Im(conj(lam_k) chi_k)
+__global__ void __launch_bounds__(256) k_hbm_diag_w(const Cplx* __restrict__ st, int64_t nvec, int n, int groups,
+                                                    float* __restrict__ wp) {
+  const int64_t N = (int64_t)1 << n;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int grp = blockIdx.y;
+  if (k >= N) return;
+  float acc = 0.f;
+  for (int64_t v = grp; v < nvec; v += groups) {
+    const Cplx x = st[v * N + k], l = st[(v + nvec) * N + k];
+    acc += l.re * x.im - l.im * x.re;
+  }
+  wp[(size_t)grp * N + k] = acc;
+}
+
+// one block per diagonal gate: acc[slot] += sum_k g(k) * sum_grp wp[grp][k],  g = +-1 (target bit), 0 if control clear
+__global__ void __launch_bounds__(256) k_hbm_diag_grad(const QcDiagGate* __restrict__ dg, const float* __restrict__ wp,
+                                                       int n, int groups, float* __restrict__ acc) {
+  __shared__ float s_red[4];
+  const QcDiagGate g = dg[blockIdx.x];
+  const int64_t N = (int64_t)1 << n;
+  float t = 0.f;
+  for (int64_t k = threadIdx.x; k < N; k += 256) {
+    if (g.bc >= 0 && !((k >> g.bc) & 1)) continue;
+    float w = 0.f;
+    for (int q = 0; q < groups; ++q) w += wp[(size_t)q * N + k];
+    t += ((k >> g.bt) & 1) ? -w : w;
+  }
+  const float tot = block_sum_256(t, s_red);
+  if (threadIdx.x == 0) acc[g.slot] += tot;
+}
+
 struct Ws {
   Cplx* chi;
   Cplx* lam;
@@ -354,28 +576,193 @@ struct Ws {
   float* wd;
   float* gblk;
   float* acc;
+  Cplx* tabs;    // [n_tables][N]
+  float* wpart;  // [W_GROUPS][N]
+  float* gpart;  // [max_param_lgates][nvec * tiles]
 };
+
+constexpr int W_GROUPS = 16;
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+inline bool use_simple() {
+  static const bool f = [] { const char* e = getenv("QC_HBM_SIMPLE"); return e && e[0] == '1'; }();
+  return f;   // test hook: one pass per gate (the staged path's cross-check)
+}
+
 }  // namespace
 
+// ------------------------------------------------------------------ plan (host)
+struct QcHbmPlanPriv {
+  QcHbmPlan pub;
+  std::vector<QcStage> stages;
+  std::vector<QcStageGate> lgates;
+  std::vector<QcDiagGate> dgates;
+  std::vector<int> slots_rev;      // per L stage: parameter slots of its parametric gates, reverse order
+  std::vector<int> slots_off;      // offset of each stage's list in slots_rev (size n_stages + 1)
+  int* d_slots_rev = nullptr;
+};
+
+static bool is_diag_op(int op) { return op == QC_RZ || op == QC_CRZ; }
+
+QcHbmPlan* qc_hbm_plan_create(const qc_program* pg) {
+  const int n = pg->n_qubits;
+  const int T = n < QC_HBM_T ? n : QC_HBM_T;
+  const int L0 = T < QC_HBM_L0 ? T : QC_HBM_L0;
+  QcHbmPlanPriv* P = new QcHbmPlanPriv();
+  struct Tmp { int kind; std::vector<int> gates; std::vector<int> extra; };
+  std::vector<Tmp> tmp;
+  for (int g = 0; g < pg->n_gates; ++g) {
+    const QcGate& gt = pg->h_gates[g];
+    if (is_diag_op(gt.op)) {
+      if (tmp.empty() || tmp.back().kind != 1) tmp.push_back({1, {}, {}});
+      tmp.back().gates.push_back(g);
+      continue;
+    }
+    std::vector<int> bits = {gt.ba};
+    if (gt.bb >= 0) bits.push_back(gt.bb);
+    std::vector<int> need;
+    const bool open_l = !tmp.empty() && tmp.back().kind == 0;
+    for (int b : bits)
+      if (b >= L0 && (!open_l || std::find(tmp.back().extra.begin(), tmp.back().extra.end(), b) == tmp.back().extra.end()) &&
+          std::find(need.begin(), need.end(), b) == need.end())
+        need.push_back(b);
+    if (open_l && (int)(tmp.back().extra.size() + need.size()) <= T - L0) {
+      for (int b : need) tmp.back().extra.push_back(b);
+      tmp.back().gates.push_back(g);
+    } else {
+      std::vector<int> ex;
+      for (int b : bits)
+        if (b >= L0 && std::find(ex.begin(), ex.end(), b) == ex.end()) ex.push_back(b);
+      tmp.push_back({0, {g}, ex});
+    }
+  }
+  int n_tables = 0, max_pl = 0;
+  P->slots_off.push_back(0);
+  for (size_t i = 0; i < tmp.size(); ++i) {
+    QcStage sd;
+    memset(&sd, 0, sizeof(sd));
+    sd.post_diag = -1;
+    sd.table = -1;
+    if (tmp[i].kind == 1) {
+      sd.kind = 1;
+      sd.g0 = (int)P->dgates.size();
+      sd.ng = (int)tmp[i].gates.size();
+      sd.table = n_tables++;
+      for (int g : tmp[i].gates) {
+        const QcGate& gt = pg->h_gates[g];
+        const bool ctl = gt.op == QC_CRZ;
+        P->dgates.push_back({gt.op, ctl ? gt.bb : gt.ba, ctl ? gt.ba : -1, g, gt.slot});
+      }
+      if (!P->stages.empty() && P->stages.back().kind == 0) {
+        P->stages.back().post_diag = (int)P->stages.size();
+        sd.fused = 1;
+      }
+    } else {
+      sd.kind = 0;
+      std::vector<int> loc;
+      for (int b = 0; b < L0; ++b) loc.push_back(b);
+      for (int b : tmp[i].extra) loc.push_back(b);
+      for (int b = L0; b < n && (int)loc.size() < T; ++b)
+        if (std::find(loc.begin(), loc.end(), b) == loc.end()) loc.push_back(b);
+      std::sort(loc.begin(), loc.end());
+      sd.nloc = (int)loc.size();
+      for (int j = 0; j < sd.nloc; ++j) sd.lb[j] = loc[j];
+      sd.ngb = 0;
+      for (int b = 0; b < n; ++b)
+        if (std::find(loc.begin(), loc.end(), b) == loc.end()) sd.gb[sd.ngb++] = b;
+      auto local = [&](int b) { return (int)(std::find(loc.begin(), loc.end(), b) - loc.begin()); };
+      sd.g0 = (int)P->lgates.size();
+      sd.ng = (int)tmp[i].gates.size();
+      std::vector<int> pslots;
+      for (int g : tmp[i].gates) {
+        const QcGate& gt = pg->h_gates[g];
+        QcStageGate lg;
+        lg.op = gt.op;
+        lg.gi = g;
+        lg.slot = gt.slot;
+        if (gt.op == QC_U4) {
+          lg.jt = local(gt.ba);
+          lg.jc = local(gt.bb);
+        } else if (gt.op == QC_CNOT || gt.op == QC_CRX) {
+          lg.jt = local(gt.bb);
+          lg.jc = local(gt.ba);
+        } else {
+          lg.jt = local(gt.ba);
+          lg.jc = -1;
+        }
+        if (gt.op != QC_U4 && gt.slot >= 0) pslots.push_back(gt.slot);
+        P->lgates.push_back(lg);
+      }
+      max_pl = std::max(max_pl, (int)pslots.size());
+      for (auto it = pslots.rbegin(); it != pslots.rend(); ++it) P->slots_rev.push_back(*it);
+    }
+    P->stages.push_back(sd);
+    P->slots_off.push_back((int)P->slots_rev.size());
+  }
+  QcHbmPlan& q = P->pub;
+  q.n_stages = (int)P->stages.size();
+  q.n_tables = n_tables;
+  q.n_lgates = (int)P->lgates.size();
+  q.n_dgates = (int)P->dgates.size();
+  q.stages = P->stages.data();
+  q.h_lgates = P->lgates.data();
+  q.h_dgates = P->dgates.data();
+  q.d_lgates = nullptr;
+  q.d_dgates = nullptr;
+  q.max_param_lgates = max_pl;
+  bool ok = true;
+  if (q.n_lgates) {
+    ok = ok && hipMalloc((void**)&q.d_lgates, sizeof(QcStageGate) * q.n_lgates) == hipSuccess;
+    ok = ok && hipMemcpy(q.d_lgates, q.h_lgates, sizeof(QcStageGate) * q.n_lgates, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (ok && q.n_dgates) {
+    ok = ok && hipMalloc((void**)&q.d_dgates, sizeof(QcDiagGate) * q.n_dgates) == hipSuccess;
+    ok = ok && hipMemcpy(q.d_dgates, q.h_dgates, sizeof(QcDiagGate) * q.n_dgates, hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (ok && !P->slots_rev.empty()) {
+    ok = ok && hipMalloc((void**)&P->d_slots_rev, sizeof(int) * P->slots_rev.size()) == hipSuccess;
+    ok = ok && hipMemcpy(P->d_slots_rev, P->slots_rev.data(), sizeof(int) * P->slots_rev.size(), hipMemcpyHostToDevice) == hipSuccess;
+  }
+  if (!ok) {
+    qc_hbm_plan_destroy(&P->pub);
+    return nullptr;
+  }
+  return &P->pub;
+}
+
+void qc_hbm_plan_destroy(QcHbmPlan* plan) {
+  if (!plan) return;
+  QcHbmPlanPriv* P = reinterpret_cast<QcHbmPlanPriv*>(plan);   // pub is the first member
+  if (plan->d_lgates) (void)hipFree(plan->d_lgates);
+  if (plan->d_dgates) (void)hipFree(plan->d_dgates);
+  if (P->d_slots_rev) (void)hipFree(P->d_slots_rev);
+  delete P;
+}
+
+// ------------------------------------------------------------------ workspace
 // bytes of workspace for one call (tile of up to 64 points at a time)
 size_t qc_hbm_workspace_bytes(const qc_program* pg, int nch, bool backward) {
   const size_t N = (size_t)1 << pg->n_qubits, T = 64;
+  const QcHbmPlan* plan = (const QcHbmPlan*)pg->hbm_plan;
   size_t b = align_up(sizeof(Cplx) * nch * T * N);                 // chi
   if (backward) {
     b += align_up(sizeof(Cplx) * nch * T * N);                     // lam (placed directly behind the used part of chi)
     b += align_up(sizeof(float) * nch * T * N);                    // series
     b += align_up(sizeof(float) * (size_t)qc_ceil_div((int64_t)nch * T * (N / 2), 256));  // gblk
     b += align_up(sizeof(float) * (pg->n_params > 0 ? pg->n_params : 1));                  // acc
+    b += align_up(sizeof(float) * W_GROUPS * N);                   // wpart
+    const size_t tiles = N >> (pg->n_qubits < QC_HBM_T ? pg->n_qubits : QC_HBM_T);
+    b += align_up(sizeof(float) * (size_t)(plan ? plan->max_param_lgates : 0) * nch * T * tiles + 256);  // gpart
   }
+  b += align_up(sizeof(Cplx) * (size_t)(plan ? plan->n_tables : 0) * N + 256);          // diagonal tables
   b += align_up(sizeof(float) * T * pg->n_qubits * 8);
   return b;
 }
 
 static Ws carve(const qc_program* pg, int nch, bool backward, void* ws) {
   const size_t N = (size_t)1 << pg->n_qubits, T = 64;
+  const QcHbmPlan* plan = (const QcHbmPlan*)pg->hbm_plan;
   char* p = (char*)ws;
   Ws w = {};
   w.chi = (Cplx*)p; p += align_up(sizeof(Cplx) * nch * T * N);
@@ -384,9 +771,81 @@ static Ws carve(const qc_program* pg, int nch, bool backward, void* ws) {
     w.ser = (float*)p; p += align_up(sizeof(float) * nch * T * N);
     w.gblk = (float*)p; p += align_up(sizeof(float) * (size_t)qc_ceil_div((int64_t)nch * T * (N / 2), 256));
     w.acc = (float*)p; p += align_up(sizeof(float) * (pg->n_params > 0 ? pg->n_params : 1));
+    w.wpart = (float*)p; p += align_up(sizeof(float) * W_GROUPS * N);
+    const size_t tiles = N >> (pg->n_qubits < QC_HBM_T ? pg->n_qubits : QC_HBM_T);
+    w.gpart = (float*)p; p += align_up(sizeof(float) * (size_t)(plan ? plan->max_param_lgates : 0) * nch * T * tiles + 256);
   }
+  w.tabs = (Cplx*)p; p += align_up(sizeof(Cplx) * (size_t)(plan ? plan->n_tables : 0) * N + 256);
   w.wd = (float*)p;
   return w;
+}
+
+// ------------------------------------------------------------------ staged forward / backward of one tile
+// dynamic LDS of a stage: 2^12 complex64 per tile, x2 with the cotangent tile = 64 KiB (the default limit)
+static void staged_forward(const qc_program* pg, const QcTrig* trig, const float* umat, const Ws& w, int64_t S,
+                           hipStream_t st) {
+  const QcHbmPlan* plan = (const QcHbmPlan*)pg->hbm_plan;
+  const int n = pg->n_qubits;
+  const int64_t N = (int64_t)1 << n;
+  for (int i = 0; i < plan->n_stages; ++i) {
+    const QcStage& sd = plan->stages[i];
+    if (sd.kind == 0) {
+      const Cplx* tab = sd.post_diag >= 0 ? w.tabs + (size_t)plan->stages[sd.post_diag].table * N : nullptr;
+      const size_t sh = sizeof(Cplx) << sd.nloc;
+      hipLaunchKernelGGL((k_hbm_stage<false, false>), dim3((unsigned)(S << sd.ngb)), dim3(256), sh, st, w.chi, S, n, sd,
+                         plan->d_lgates, trig, umat, tab, (float*)nullptr);
+    } else if (!sd.fused) {
+      hipLaunchKernelGGL((k_hbm_diag_apply<false>), dim3(qc_ceil_div(S * N, 256)), dim3(256), 0, st, w.chi, S, n,
+                         w.tabs + (size_t)sd.table * N);
+    }
+  }
+}
+
+static void build_tables(const qc_program* pg, const QcTrig* trig, const Ws& w, hipStream_t st) {
+  const QcHbmPlan* plan = (const QcHbmPlan*)pg->hbm_plan;
+  const int n = pg->n_qubits;
+  const int64_t N = (int64_t)1 << n;
+  for (int i = 0; i < plan->n_stages; ++i) {
+    const QcStage& sd = plan->stages[i];
+    if (sd.kind == 1)
+      hipLaunchKernelGGL(k_hbm_diag_table, dim3(qc_ceil_div(N, 256)), dim3(256), 0, st, plan->d_dgates + sd.g0, sd.ng, trig, n,
+                         w.tabs + (size_t)sd.table * N);
+  }
+}
+
+static void staged_backward(const qc_program* pg, const QcTrig* trig, const float* umat, const Ws& w, int64_t S,
+                            hipStream_t st) {
+  const QcHbmPlanPriv* P = reinterpret_cast<const QcHbmPlanPriv*>(pg->hbm_plan);
+  const QcHbmPlan* plan = &P->pub;
+  const int n = pg->n_qubits;
+  const int64_t N = (int64_t)1 << n;
+  auto diag_grads = [&](const QcStage& d) {   // memory holds chi, lam at the OUTPUT of the diagonal run d
+    hipLaunchKernelGGL(k_hbm_diag_w, dim3(qc_ceil_div(N, 256), W_GROUPS), dim3(256), 0, st, w.chi, S, n, W_GROUPS, w.wpart);
+    hipLaunchKernelGGL(k_hbm_diag_grad, dim3(d.ng), dim3(256), 0, st, plan->d_dgates + d.g0, w.wpart, n, W_GROUPS, w.acc);
+  };
+  for (int i = plan->n_stages - 1; i >= 0; --i) {
+    const QcStage& sd = plan->stages[i];
+    if (sd.kind == 0) {
+      const Cplx* tab = nullptr;
+      if (sd.post_diag >= 0) {
+        const QcStage& d = plan->stages[sd.post_diag];
+        diag_grads(d);
+        tab = w.tabs + (size_t)d.table * N;
+      }
+      const size_t sh = 2 * (sizeof(Cplx) << sd.nloc);
+      const unsigned nblk = (unsigned)(S << sd.ngb);
+      hipLaunchKernelGGL((k_hbm_stage<true, true>), dim3(nblk), dim3(256), sh, st, w.chi, S, n, sd, plan->d_lgates, trig, umat,
+                         tab, w.gpart);
+      const int np = P->slots_off[i + 1] - P->slots_off[i];
+      if (np > 0)
+        hipLaunchKernelGGL(k_hbm_fold_stage, dim3(np), dim3(256), 0, st, w.gpart, (int)nblk, P->d_slots_rev + P->slots_off[i],
+                           w.acc);
+    } else if (!sd.fused) {
+      diag_grads(sd);
+      hipLaunchKernelGGL((k_hbm_diag_apply<true>), dim3(qc_ceil_div(2 * S * N, 256)), dim3(256), 0, st, w.chi, 2 * S, n,
+                         w.tabs + (size_t)sd.table * N);
+    }
+  }
 }
 
 template <int NCH>
@@ -398,6 +857,8 @@ static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* um
   const int n = pg->n_qubits;
   const int64_t N = (int64_t)1 << n;
   Ws w = carve(pg, NCH, backward, ws);
+  const bool staged = pg->hbm_plan != nullptr && !use_simple();
+  if (staged) build_tables(pg, trig_dev, w, st);
   for (int64_t p0 = 0; p0 < B; p0 += 64) {
     const int T = (int)((B - p0) < 64 ? (B - p0) : 64);
     const int TA = T;                                   // layout stride = points of this tile
@@ -409,7 +870,8 @@ static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* um
     else
       hipLaunchKernelGGL((k_hbm_init<NCH, false>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n, w.chi, w.ser);
     const int64_t S = (int64_t)NCH * TA;
-    for (int g = 0; g < pg->n_gates; ++g) {
+    if (staged) staged_forward(pg, trig_dev, umat, w, S, st);
+    for (int g = 0; g < pg->n_gates && !staged; ++g) {
       const QcGate gt = pg->h_gates[g];
       if (gt.op == QC_U4)
         hipLaunchKernelGGL(k_hbm_u4, dim3(qc_ceil_div(S * (N / 4), 256)), dim3(256), 0, st, w.chi, S, n, gt.ba, gt.bb,
@@ -426,7 +888,8 @@ static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* um
     hipLaunchKernelGGL(k_hbm_zero, dim3(qc_ceil_div(pg->n_params > 0 ? pg->n_params : 1, 256)), dim3(256), 0, st, w.acc,
                        pg->n_params > 0 ? pg->n_params : 1);
     const int nblk = qc_ceil_div(S * (N / 2), 256);
-    for (int g = pg->n_gates - 1; g >= 0; --g) {
+    if (staged) staged_backward(pg, trig_dev, umat, w, S, st);
+    for (int g = pg->n_gates - 1; g >= 0 && !staged; --g) {
       const QcGate gt = pg->h_gates[g];
       if (gt.op == QC_U4) {
         hipLaunchKernelGGL(k_hbm_u4, dim3(qc_ceil_div(2 * S * (N / 4), 256)), dim3(256), 0, st, w.chi, 2 * S, n, gt.ba, gt.bb,

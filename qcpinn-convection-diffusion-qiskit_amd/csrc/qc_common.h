@@ -36,6 +36,7 @@ struct qc_program {
   int static_id;    // index into the compile-time specialised programs, or -1
   QcGate* d_gates;  // device
   QcGate* h_gates;  // host copy
+  void* hbm_plan;   // QcHbmPlan* for n >= 9 (staged execution), else null
 };
 
 // Channel numbering of the derivative ("jet") channels carried through the network:
