@@ -133,3 +133,18 @@ def test_wave_family_agrees_with_oracle_at_small_n():
                         "-x", "-k", sel], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def test_hbm_per_gate_path_agrees_with_staged_path():
+    """n >= 9: the staged plan (LDS tiles + fused diagonal tables) is the default; QC_HBM_SIMPLE=1 selects
+    the one-pass-per-gate form.  Both must pass the same golden / oracle checks (child process: the
+    switch is read once at library load)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, QC_HBM_SIMPLE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "(golden and (n10 or n16)) or (vjp and (cascade-9 or layered-10))"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_circuit.py"), "-m", "gpu", "-q",
+                        "-x", "-k", sel], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "4 passed" in r.stdout
