@@ -143,7 +143,7 @@ def test_hbm_per_gate_path_agrees_with_staged_path():
     import sys
     env = dict(os.environ, QC_HBM_SIMPLE="1")
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "(golden and (n10 or n16)) or (vjp and (cascade-9 or layered-10))"
+    sel = "(golden and (n10 or n16)) or (expval_vjp and (cascade-9 or layered-10))"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_circuit.py"), "-m", "gpu", "-q",
                         "-x", "-k", sel], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
