@@ -26,37 +26,52 @@ class Sampler:
         return pts, self.func(pts.to(self.device))
 
 
-def _split(txy):
-    return txy[:, 0:1], txy[:, 1:2], txy[:, 2:3]
+def _parts(txy):
+    """(u, x - 1/2, y - 1/2) of the Gaussian pulse u = exp(-100 |(x, y) - (1/2, 1/2)|^2) * exp(-t)."""
+    dx = txy[:, 1:2] - 0.5
+    dy = txy[:, 2:3] - 0.5
+    val = torch.exp(-100 * (dx ** 2 + dy ** 2)) * torch.exp(-txy[:, 0:1])
+    return val, dx, dy
 
 
 def u(txy):
-    t, x, y = _split(txy)
-    return torch.exp(-100 * ((x - 0.5) ** 2 + (y - 0.5) ** 2)) * torch.exp(-t)
+    return _parts(txy)[0]
 
 
 def u_t(txy):
-    return -u(txy)
+    return -_parts(txy)[0]
 
 
 def u_x(txy):
-    return -200 * (txy[:, 1:2] - 0.5) * u(txy)
+    val, dx, _ = _parts(txy)
+    return -200 * dx * val
 
 
 def u_y(txy):
-    return -200 * (txy[:, 2:3] - 0.5) * u(txy)
+    val, _, dy = _parts(txy)
+    return -200 * dy * val
+
+
+# Second derivatives as the reference writes them: the constant is -400 where d2/dx2 of the pulse
+# gives -200 (data/diffusion_dataset.py:31-34).  Kept on purpose: `r` below is the training target.
+_REF_CONST = 400
 
 
 def u_xx(txy):
-    return (40000 * (txy[:, 1:2] - 0.5) ** 2 - 400) * u(txy)      # sic: reference constant
+    val, dx, _ = _parts(txy)
+    return (40000 * dx ** 2 - _REF_CONST) * val
 
 
 def u_yy(txy):
-    return (40000 * (txy[:, 2:3] - 0.5) ** 2 - 400) * u(txy)      # sic: reference constant
+    val, _, dy = _parts(txy)
+    return (40000 * dy ** 2 - _REF_CONST) * val
 
 
 def r(txy, Diffusion=default_D, v_x=default_v_x, v_y=default_v_y):
-    return u_t(txy) + v_x * u_x(txy) + v_y * u_y(txy) - Diffusion * (u_xx(txy) + u_yy(txy))
+    val, dx, dy = _parts(txy)
+    first = -val - 200 * val * (v_x * dx + v_y * dy)
+    second = (40000 * (dx ** 2 + dy ** 2) - 2 * _REF_CONST) * val
+    return first - Diffusion * second
 
 
 BOXES = {  # [[t,x,y] low, high]  (trainer/diffusion_train.py:9-20)
