@@ -186,13 +186,19 @@ def main():
                      "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # "nccl" is RCCL on ROCm (xGMI).  QC_BENCH_BACKEND=gloo exists only to rehearse the multi-rank
+        # control flow on a single-GPU box (all ranks share cuda:0).
+        backend = os.environ.get("QC_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     Solver = importlib.import_module(PKG + ".nn.DVPDESolver").DVPDESolver
     trainer = importlib.import_module(PKG + ".trainer.diffusion_train")
