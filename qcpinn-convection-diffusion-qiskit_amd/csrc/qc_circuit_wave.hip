@@ -91,17 +91,53 @@ __device__ __forceinline__ float grad_term(int op, bool t, bool cnd, float lr, f
 
 __device__ __forceinline__ bool op_needs_partner(int op) { return !(op == QC_RZ || op == QC_CRZ); }
 
-// One non-U4 gate on K vectors.  GRAD: vectors [0,K/2) are chi, [K/2,K) are lam; returns this lane's
-// partial of sum_c Im<lam_c|G|chi_c> evaluated BEFORE the (adjoint) update.
-template <int LR, int K, bool ADJ, bool GRAD>
-__device__ __forceinline__ float wave_gate(WV<LR> (&v)[K], const QcGate g, const float c, const float s_in,
-                                           const Grp& G) {
+// ---- op-specialised 2x2 updates.  Per-lane real coefficients (c1, s1) fold in the control predicate
+// (identity where the control bit is clear) and the sign that depends on this amplitude's target bit,
+// so every update is 2 mul + 2 fma with no select.
+struct LaneCoef {
+  float c1;   // multiplies the amplitude itself
+  float s1;   // multiplies the partner (or, for RZ, the other component of the amplitude itself)
+};
+
+template <int OP>
+__device__ __forceinline__ LaneCoef lane_coef(float c, float s, bool t, bool cnd) {
+  if constexpr (OP == QC_RX || OP == QC_CRX) return {cnd ? c : 1.f, cnd ? s : 0.f};
+  else if constexpr (OP == QC_RY) return {c, t ? s : -s};
+  else if constexpr (OP == QC_RZ || OP == QC_CRZ) return {cnd ? c : 1.f, cnd ? (t ? -s : s) : 0.f};
+  else if constexpr (OP == QC_H) return {t ? -0.70710678118654752440f : 0.70710678118654752440f, 0.70710678118654752440f};
+  else return {cnd ? 0.f : 1.f, cnd ? 1.f : 0.f};   // CNOT: partner where the control is set
+}
+
+// a' for amplitude (ar, ai) with partner (pr, pi)
+template <int OP>
+__device__ __forceinline__ void apply_op(float& ar, float& ai, float pr, float pi, LaneCoef k) {
+  const float r0 = ar, i0 = ai;
+  if constexpr (OP == QC_RX || OP == QC_CRX) {          // c a - i s p
+    ar = fmaf(k.s1, pi, k.c1 * r0);
+    ai = fmaf(-k.s1, pr, k.c1 * i0);
+  } else if constexpr (OP == QC_RY) {                    // c a -+ s p
+    ar = fmaf(k.s1, pr, k.c1 * r0);
+    ai = fmaf(k.s1, pi, k.c1 * i0);
+  } else if constexpr (OP == QC_RZ || OP == QC_CRZ) {    // (c - i s1) a
+    ar = fmaf(k.s1, i0, k.c1 * r0);
+    ai = fmaf(-k.s1, r0, k.c1 * i0);
+  } else {                                               // H, CNOT: c1 a + s1 p
+    ar = fmaf(k.s1, pr, k.c1 * r0);
+    ai = fmaf(k.s1, pi, k.c1 * i0);
+  }
+}
+
+// One non-U4 gate of compile-time kind OP on K vectors.  GRAD: vectors [0,K/2) are chi, [K/2,K) are
+// lam; returns this lane's partial of sum_c Im<lam_c|G|chi_c> evaluated BEFORE the (adjoint) update.
+template <int LR, int K, bool ADJ, bool GRAD, int OP>
+__device__ __forceinline__ float wave_gate_op(WV<LR> (&v)[K], const QcGate g, const float c, const float s_in,
+                                              const Grp& G) {
   constexpr int R = 1 << LR;
+  constexpr bool ctl = (OP == QC_CNOT || OP == QC_CRX || OP == QC_CRZ);
+  constexpr bool needp = !(OP == QC_RZ || OP == QC_CRZ);
   const float s = ADJ ? -s_in : s_in;
-  const bool ctl = (g.op == QC_CNOT || g.op == QC_CRX || g.op == QC_CRZ);
   const int tb = ctl ? g.bb : g.ba;
   const int cb = ctl ? g.ba : -1;
-  const bool needp = op_needs_partner(g.op);
   float grad = 0.f;
 
   if (tb >= LR) {  // ---- target on a lane bit
@@ -109,26 +145,24 @@ __device__ __forceinline__ float wave_gate(WV<LR> (&v)[K], const QcGate g, const
     const bool t = (G.sub >> (tb - LR)) & 1;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const bool cnd = cb < 0 ? true : bitval<LR>(cb, r, G.sub);
-      const Coef k = gate_coef(g.op, c, s, t, cnd);
+      const bool cnd = ctl ? bitval<LR>(cb, r, G.sub) : true;
+      const LaneCoef k = lane_coef<OP>(c, s, t, cnd);
 #pragma unroll
       for (int q = 0; q < K; ++q) {
-        const float ar = v[q].re[r], ai = v[q].im[r];
+        float ar = v[q].re[r], ai = v[q].im[r];
         float pr = 0.f, pi = 0.f;
-        if (needp) {
+        if constexpr (needp) {
           pr = __shfl_xor(ar, mask);
           pi = __shfl_xor(ai, mask);
         }
         if constexpr (GRAD) {
-          if (q < K / 2) {
-            grad += grad_term(g.op, t, cnd, v[q + K / 2].re[r], v[q + K / 2].im[r], ar, ai, pr, pi);
-          }
+          if (q < K / 2) grad += grad_term(OP, t, cnd, v[q + K / 2].re[r], v[q + K / 2].im[r], ar, ai, pr, pi);
         }
-        v[q].re[r] = k.ar * ar - k.ai * ai + k.br * pr - k.bi * pi;
-        v[q].im[r] = k.ar * ai + k.ai * ar + k.br * pi + k.bi * pr;
+        apply_op<OP>(ar, ai, pr, pi, k);
+        v[q].re[r] = ar;
+        v[q].im[r] = ai;
       }
     }
-    // GRAD reads lam (q >= K/2) before it is updated only if chi comes first: true, q ascending.
   } else {  // ---- target on a register bit: static pairs via a switch on the bit
     auto body = [&](auto TBC) {
       constexpr int TB = decltype(TBC)::value;
@@ -137,21 +171,24 @@ __device__ __forceinline__ float wave_gate(WV<LR> (&v)[K], const QcGate g, const
         for (int h = 0; h < R / 2; ++h) {
           const int r0 = ((h >> TB) << (TB + 1)) | (h & ((1 << TB) - 1));
           const int r1 = r0 | (1 << TB);
-          const bool cnd = cb < 0 ? true : bitval<LR>(cb, r0, G.sub);
-          const Coef k0 = gate_coef(g.op, c, s, false, cnd), k1 = gate_coef(g.op, c, s, true, cnd);
+          const bool cnd = ctl ? bitval<LR>(cb, r0, G.sub) : true;
+          const LaneCoef k0 = lane_coef<OP>(c, s, false, cnd), k1 = lane_coef<OP>(c, s, true, cnd);
 #pragma unroll
           for (int q = 0; q < K; ++q) {
-            const float ar = v[q].re[r0], ai = v[q].im[r0], br = v[q].re[r1], bi = v[q].im[r1];
+            float ar = v[q].re[r0], ai = v[q].im[r0], br = v[q].re[r1], bi = v[q].im[r1];
             if constexpr (GRAD) {
               if (q < K / 2) {
-                grad += grad_term(g.op, false, cnd, v[q + K / 2].re[r0], v[q + K / 2].im[r0], ar, ai, br, bi);
-                grad += grad_term(g.op, true, cnd, v[q + K / 2].re[r1], v[q + K / 2].im[r1], br, bi, ar, ai);
+                grad += grad_term(OP, false, cnd, v[q + K / 2].re[r0], v[q + K / 2].im[r0], ar, ai, br, bi);
+                grad += grad_term(OP, true, cnd, v[q + K / 2].re[r1], v[q + K / 2].im[r1], br, bi, ar, ai);
               }
             }
-            v[q].re[r0] = k0.ar * ar - k0.ai * ai + k0.br * br - k0.bi * bi;
-            v[q].im[r0] = k0.ar * ai + k0.ai * ar + k0.br * bi + k0.bi * br;
-            v[q].re[r1] = k1.ar * br - k1.ai * bi + k1.br * ar - k1.bi * ai;
-            v[q].im[r1] = k1.ar * bi + k1.ai * br + k1.br * ai + k1.bi * ar;
+            const float a0r = ar, a0i = ai;
+            apply_op<OP>(ar, ai, br, bi, k0);
+            apply_op<OP>(br, bi, a0r, a0i, k1);
+            v[q].re[r0] = ar;
+            v[q].im[r0] = ai;
+            v[q].re[r1] = br;
+            v[q].im[r1] = bi;
           }
         }
       }
@@ -165,6 +202,22 @@ __device__ __forceinline__ float wave_gate(WV<LR> (&v)[K], const QcGate g, const
     }
   }
   return grad;
+}
+
+// run-time opcode -> compile-time kind (wave-uniform branch)
+template <int LR, int K, bool ADJ, bool GRAD>
+__device__ __forceinline__ float wave_gate(WV<LR> (&v)[K], const QcGate g, const float c, const float s_in,
+                                           const Grp& G) {
+  switch (g.op) {
+    case QC_RX: return wave_gate_op<LR, K, ADJ, GRAD, QC_RX>(v, g, c, s_in, G);
+    case QC_RY: return wave_gate_op<LR, K, ADJ, GRAD, QC_RY>(v, g, c, s_in, G);
+    case QC_RZ: return wave_gate_op<LR, K, ADJ, GRAD, QC_RZ>(v, g, c, s_in, G);
+    case QC_H: return wave_gate_op<LR, K, ADJ, GRAD, QC_H>(v, g, c, s_in, G);
+    case QC_CNOT: return wave_gate_op<LR, K, ADJ, GRAD, QC_CNOT>(v, g, c, s_in, G);
+    case QC_CRX: return wave_gate_op<LR, K, ADJ, GRAD, QC_CRX>(v, g, c, s_in, G);
+    case QC_CRZ: return wave_gate_op<LR, K, ADJ, GRAD, QC_CRZ>(v, g, c, s_in, G);
+    default: return 0.f;
+  }
 }
 
 // Fixed two-wire unitary on lane bits (wires [0,1] / [2,3] are always lane bits in this layout).
