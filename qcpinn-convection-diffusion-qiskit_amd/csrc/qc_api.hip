@@ -341,7 +341,6 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
   if (rows <= 0 || rows > d->part_rows_cap || d->part_stride < L.NP + 3) return QC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const QcTrig* trig = (const QcTrig*)d->trig_dev;
-  const QcPde pde = to_pde(&d->pde);
 
   if (phases & QC_PHASE_SAMPLE) {
     if ((rc = qc_sample_collocation((float*)d->X_res_dev, d->B_res, d->sample_off_res, (float*)d->X_val_dev, d->n_ic,

@@ -9,9 +9,10 @@
 // (ds_bpermute, the LDS crossbar, no LDS storage), a gate on a register bit is lane-local, and
 // <Z_w> is a butterfly reduction over the group's lanes.
 //
-// Every gate is applied in the 2-term form a' = alpha*a + beta*partner with per-lane complex
-// coefficients derived from (opcode, bit of this amplitude, control predicate), which keeps ONE code
-// path for RX/RY/RZ/H/CNOT/CRX/CRZ with run-time wires.
+// The gate PROGRAM is run-time data (any ansatz); the opcode selects (wave-uniform branch) an
+// op-specialised body: a' = c1*a + s1*partner with per-lane REAL coefficients that fold in the control
+// predicate and the sign given by this amplitude's target bit: 2 mul + 2 fma per amplitude, no select;
+// wires stay run-time values (lane-bit masks for __shfl_xor, register-bit switch).
 //
 // A block is 4 waves = one 64-point tile (one gradient partial row); each wave walks its 16 points.
 #include "qc_internal.h"
@@ -39,38 +40,6 @@ __device__ __forceinline__ bool bitval(int b, int r, int sub) {
   return b < LR ? ((r >> b) & 1) : ((sub >> (b - LR)) & 1);
 }
 
-struct Coef {
-  float ar, ai, br, bi;
-};
-
-// alpha/beta of a' = alpha*a + beta*partner for the amplitude whose target bit is t, control cnd.
-__device__ __forceinline__ Coef gate_coef(int op, float c, float s, bool t, bool cnd) {
-  Coef k = {1.f, 0.f, 0.f, 0.f};
-  if (!cnd) return k;
-  switch (op) {
-    case QC_RX:
-    case QC_CRX:
-      k = {c, 0.f, 0.f, -s};
-      break;
-    case QC_RY:
-      k = {c, 0.f, t ? s : -s, 0.f};
-      break;
-    case QC_RZ:
-    case QC_CRZ:
-      k = {c, t ? s : -s, 0.f, 0.f};
-      break;
-    case QC_H:
-      k = {t ? -0.70710678118654752440f : 0.70710678118654752440f, 0.f, 0.70710678118654752440f, 0.f};
-      break;
-    case QC_CNOT:
-      k = {0.f, 0.f, 1.f, 0.f};
-      break;
-    default:
-      break;
-  }
-  return k;
-}
-
 // per-amplitude contribution to Im<lam|G|chi>: (lr,li) = lam, (xr,xi) = chi, (pr,pi) = chi's partner
 __device__ __forceinline__ float grad_term(int op, bool t, bool cnd, float lr, float li, float xr, float xi,
                                            float pr, float pi) {
@@ -88,8 +57,6 @@ __device__ __forceinline__ float grad_term(int op, bool t, bool cnd, float lr, f
       return 0.f;
   }
 }
-
-__device__ __forceinline__ bool op_needs_partner(int op) { return !(op == QC_RZ || op == QC_CRZ); }
 
 // ---- op-specialised 2x2 updates.  Per-lane real coefficients (c1, s1) fold in the control predicate
 // (identity where the control bit is clear) and the sign that depends on this amplitude's target bit,
