@@ -42,6 +42,14 @@ int qc_last_hip_error(void); /* hipError_t of the last failing runtime call, 0 i
 int qc_program_create(const int32_t* gate_rows, int n_gates, int n_qubits, int n_params, qc_program** out);
 int qc_program_destroy(qc_program* prog);
 size_t qc_trig_bytes(const qc_program* prog); /* size of the per-gate cos/sin workspace */
+/* 0 (default): AngleEmbedding, RX(x_i) on wire i (nn/DVQuantumLayer.py:182).  1: AmplitudeEmbedding(normalize=True,
+ * pad_with=0) (:177-180); the circuit entry points then take the jets of the INITIAL AMPLITUDES (see
+ * qc_amp_forward) where they take angle jets otherwise, and return cotangents w.r.t. them. */
+int qc_program_set_encoding(qc_program* prog, int amplitude);
+/* angle-jet layout [nch][n][B] -> jets of u = a/|a| (same layout), and the pull-back of their cotangents */
+int qc_amp_forward(const float* ajets_dev, float* ujets_dev, int n, int64_t B, int nch, void* stream);
+int qc_amp_backward(const float* ajets_dev, const float* ubar_dev, float* abar_dev, int n, int64_t B, int nch,
+                    void* stream);
 
 /* cos/sin(theta/2) per gate; call after theta changes (the fused step does it itself). */
 int qc_prepare_gates(const qc_program* prog, const float* theta_dev, void* trig_dev, void* stream);
@@ -154,13 +162,14 @@ typedef struct qc_step_desc {
   int64_t n_ic;                 /* leading IC points of the value batch (== pde.n_seg_a) */
   int64_t sample_off_res, sample_off_ic, sample_off_bc;
   uint64_t sample_seed, sample_step;
-  void* circ_ws_dev; size_t circ_ws_bytes;   /* qc_step_workspace_bytes(prog, B_res); NULL/0 allowed when n <= 8 */
+  void* circ_ws_dev; size_t circ_ws_bytes;   /* qc_step_workspace_bytes(prog, B_res, B_val); NULL/0 allowed for angle encoding at n <= 8 */
 } qc_step_desc;
 
 /* Scratch for one fused step on B_res residual points: the HBM statevector tile for n >= 9; for the
  * register family (2 <= n <= 5) an optional [6][2*2^n][B_res] store of the forward pass's final states
- * that lets the adjoint kernel skip recomputing them (pass less and it recomputes). */
-size_t qc_step_workspace_bytes(const qc_program* prog, int64_t B_res);
+ * that lets the adjoint kernel skip recomputing them (pass less and it recomputes); with amplitude encoding
+ * additionally the initial-amplitude jets and their cotangents of both pipelines (required). */
+size_t qc_step_workspace_bytes(const qc_program* prog, int64_t B_res, int64_t B_val);
 
 #define QC_PHASE_GRADS 1
 #define QC_PHASE_UPDATE 2

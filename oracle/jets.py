@@ -14,17 +14,17 @@ import torch
 from . import statevector as sv
 
 
-def qjets_from_ajets(ajets, params, q_ansatz, n, haar=None):
+def qjets_from_ajets(ajets, params, q_ansatz, n, haar=None, encoding="angle"):
     """ajets: (6, n, B) float64 (may require grad); returns (6, n, B) float64, differentiable."""
     B = ajets.shape[2]
     a0 = ajets[0].T                                                       # (B, n)
-    chans = {0: sv.circuit_expvals(a0, params, q_ansatz, n, haar)}        # (n, B)
+    chans = {0: sv.circuit_expvals(a0, params, q_ansatz, n, haar, encoding)}        # (n, B)
     for k in (1, 2, 3):
         eps = torch.zeros(B, dtype=torch.float64, requires_grad=True)
         curve = a0 + eps[:, None] * ajets[k].T
         if k >= 2:
             curve = curve + 0.5 * eps[:, None] ** 2 * ajets[k + 2].T
-        q = sv.circuit_expvals(curve, params, q_ansatz, n, haar)
+        q = sv.circuit_expvals(curve, params, q_ansatz, n, haar, encoding)
         q1 = torch.stack([torch.autograd.grad(q[i].sum(), eps, create_graph=True)[0] for i in range(n)])
         chans[k] = q1
         if k >= 2:

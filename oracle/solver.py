@@ -43,9 +43,11 @@ class OracleQuantumLayer(nn.Module):
         self.haar_seed1 = seed
         self.haar_seed2 = seed + 1 if seed is not None else None
         self._haar = sv.haar_pair(self.haar_seed1, self.haar_seed2)
+        self.encoding = args.get("encoding", "angle")
 
     def forward(self, x):
-        return sv.circuit_expvals(x, self.params, self.q_ansatz, self.num_qubits, self._haar)
+        return sv.circuit_expvals(x, self.params, self.q_ansatz, self.num_qubits, self._haar,
+                                  "amplitude" if self.encoding == "amplitude" else "angle")
 
 
 class _NullLogger:

@@ -217,7 +217,7 @@ def haar_pair(seed1: Optional[int], seed2: Optional[int]):
 
 
 def circuit_expvals(x: torch.Tensor, params: torch.Tensor, q_ansatz: str, n: int,
-                    haar=None) -> torch.Tensor:
+                    haar=None, encoding: str = "angle") -> torch.Tensor:
     """``DVQuantumLayer.forward`` batch branch (nn/DVQuantumLayer.py:151-154,176-214).
 
     x: (B, n) real angles; params: (L, P) real.  Returns (n, B) float64 — the ``torch.stack`` of
@@ -225,8 +225,14 @@ def circuit_expvals(x: torch.Tensor, params: torch.Tensor, q_ansatz: str, n: int
     x = x.to(RDT)
     params = params.to(RDT)
     sim = Simulator(n, x.shape[0])
-    for w in range(n):                                       # AngleEmbedding, rotation="X"  (:182)
-        sim.RX(x[:, w], w)
+    if encoding == "amplitude":                              # AmplitudeEmbedding(normalize=True, pad_with=0.0)  (:177-180)
+        padded = torch.zeros(x.shape[0], 1 << n, dtype=RDT)
+        padded = torch.cat([x, padded[:, x.shape[1]:]], dim=1)
+        padded = padded / padded.norm(dim=1, keepdim=True)
+        sim.state = padded.to(CDT).reshape((x.shape[0],) + (2,) * n)
+    else:
+        for w in range(n):                                   # AngleEmbedding, rotation="X"  (:182)
+            sim.RX(x[:, w], w)
     for layer in range(params.shape[0]):                     # :184-201
         ANSATZ[q_ansatz](sim, params[layer])
     if haar is not None:                                     # :203-209

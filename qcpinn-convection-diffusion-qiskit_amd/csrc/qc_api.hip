@@ -116,6 +116,7 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   p->h_gates = h; p->d_gates = nullptr;
   p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p) : -1;
   p->hbm_plan = nullptr;
+  p->amplitude = 0;
   hipError_t e = hipMalloc((void**)&p->d_gates, sizeof(QcGate) * n_gates);
   if (e == hipSuccess) e = hipMemcpy(p->d_gates, h, sizeof(QcGate) * n_gates, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -146,6 +147,25 @@ int qc_program_destroy(qc_program* p) {
   return QC_OK;
 }
 
+int qc_program_set_encoding(qc_program* p, int amplitude) {
+  if (!p || (amplitude != 0 && amplitude != 1)) return QC_ERR_ARG;
+  if (amplitude && ((int64_t)1 << p->n_qubits) < p->n_qubits) return QC_ERR_ARG;
+  p->amplitude = amplitude;
+  return QC_OK;
+}
+
+int qc_amp_forward(const float* ajets, float* ujets, int n, int64_t B, int nch, void* stream) {
+  if (!ajets || !ujets || n < 1 || n > 24 || B <= 0 || (nch != 1 && nch != 6)) return QC_ERR_ARG;
+  qc_amp_fwd_launch(ajets, ujets, n, B, nch, (hipStream_t)stream);
+  return after_launch();
+}
+
+int qc_amp_backward(const float* ajets, const float* ubar, float* abar, int n, int64_t B, int nch, void* stream) {
+  if (!ajets || !ubar || !abar || n < 1 || n > 24 || B <= 0 || (nch != 1 && nch != 6)) return QC_ERR_ARG;
+  qc_amp_bwd_launch(ajets, ubar, abar, n, B, nch, (hipStream_t)stream);
+  return after_launch();
+}
+
 size_t qc_trig_bytes(const qc_program* p) { return p ? sizeof(QcTrig) * (size_t)p->n_gates : 0; }
 
 int qc_prepare_gates(const qc_program* p, const float* theta, void* trig, void* stream) {
@@ -166,11 +186,19 @@ size_t qc_circuit_workspace_bytes(const qc_program* p, int nch, int backward) {
   return qc_hbm_workspace_bytes(p, nch, backward != 0);
 }
 
-size_t qc_step_workspace_bytes(const qc_program* p, int64_t B_res) {
-  if (!p || B_res < 0) return 0;
+static size_t step_circuit_bytes(const qc_program* p, int64_t B_res) {
   if (use_hbm(p->n_qubits)) return qc_hbm_workspace_bytes(p, 6, true);
   if (use_reg(p->n_qubits)) return qc_reg_chi_store_bytes(p, B_res);   // optional: enables the no-recompute adjoint
   return 0;
+}
+static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t qc_step_workspace_bytes(const qc_program* p, int64_t B_res, int64_t B_val) {
+  if (!p || B_res < 0 || B_val < 0) return 0;
+  size_t b = round256(step_circuit_bytes(p, B_res));
+  if (p->amplitude)   // initial-amplitude jets and their cotangents, both pipelines
+    b += 2 * round256(sizeof(float) * 6 * p->n_qubits * (size_t)B_res) + 2 * round256(sizeof(float) * p->n_qubits * (size_t)B_val);
+  return b;
 }
 
 int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, const float* angles,
@@ -341,6 +369,21 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
   if (rows <= 0 || rows > d->part_rows_cap || d->part_stride < L.NP + 3) return QC_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   const QcTrig* trig = (const QcTrig*)d->trig_dev;
+  // amplitude encoding: the circuit kernels run on the initial-amplitude jets u(a) and return cotangents
+  // w.r.t. them; both live behind the circuit scratch in the step workspace
+  const bool amp = d->prog->amplitude != 0;
+  float *u_res = nullptr, *ub_res = nullptr, *u_val = nullptr, *ub_val = nullptr;
+  void* cws = d->circ_ws_dev;
+  size_t cws_bytes = d->circ_ws_bytes;
+  if (amp) {
+    if (!d->circ_ws_dev || d->circ_ws_bytes < qc_step_workspace_bytes(d->prog, d->B_res, d->B_val)) return QC_ERR_ARG;
+    char* base = (char*)d->circ_ws_dev + round256(step_circuit_bytes(d->prog, d->B_res));
+    const size_t rb = round256(sizeof(float) * 6 * n * (size_t)d->B_res), vb = round256(sizeof(float) * n * (size_t)d->B_val);
+    u_res = (float*)base; ub_res = (float*)(base + rb);
+    u_val = (float*)(base + 2 * rb); ub_val = (float*)(base + 2 * rb + vb);
+    cws_bytes = round256(step_circuit_bytes(d->prog, d->B_res));
+    if (cws_bytes == 0) cws = nullptr;
+  }
 
   if (phases & QC_PHASE_SAMPLE) {
     if ((rc = qc_sample_collocation((float*)d->X_res_dev, d->B_res, d->sample_off_res, (float*)d->X_val_dev, d->n_ic,
@@ -362,14 +405,16 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (!d->X_val_dev || !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
         return QC_ERR_ARG;
       if ((rc = qc_pre_forward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->ajets_val_dev, d->B_val, 1, sv))) return rc;
-      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qjets_val_dev, d->B_val, d->circ_ws_dev,
-                                  d->circ_ws_bytes, sv))) return rc;
+      if (amp && (rc = qc_amp_forward(d->ajets_val_dev, u_val, n, d->B_val, 1, sv))) return rc;
+      const float* cin_val = amp ? u_val : d->ajets_val_dev;
+      float* cout_val = amp ? ub_val : d->abar_val_dev;
+      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, cin_val, d->qjets_val_dev, d->B_val, cws, cws_bytes, sv))) return rc;
       if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev,
                         d->abar_val_dev, nullptr, nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride,
                         rows_res, d->B_val, 1, sv))) return rc;
-      if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev,
-                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, d->circ_ws_dev, d->circ_ws_bytes,
-                                   sv))) return rc;
+      if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, cin_val, d->qbar_val_dev, cout_val,
+                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, cws, cws_bytes, sv))) return rc;
+      if (amp && (rc = qc_amp_backward(d->ajets_val_dev, ub_val, d->abar_val_dev, n, d->B_val, 1, sv))) return rc;
       if ((rc = qc_pre_backward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->abar_val_dev, d->part_dev,
                                 d->part_stride, rows_res, d->B_val, 1, sv))) return rc;
     }
@@ -378,25 +423,27 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
         return QC_ERR_ARG;
       if ((rc = qc_pre_forward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->ajets_res_dev, d->B_res, 6, st))) return rc;
       // register family: keep the final states of the forward pass for the adjoint kernel of this step
-      float* chi_store = (use_reg(n) && d->circ_ws_dev && d->circ_ws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res))
-                             ? (float*)d->circ_ws_dev : nullptr;
+      float* chi_store = (use_reg(n) && cws && cws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res)) ? (float*)cws : nullptr;
+      if (amp && (rc = qc_amp_forward(d->ajets_res_dev, u_res, n, d->B_res, 6, st))) return rc;
+      const float* cin_res = amp ? u_res : d->ajets_res_dev;
+      float* cout_res = amp ? ub_res : d->abar_res_dev;
       if (use_reg(n)) {
-        if ((rc = qc_reg_jets_fwd(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, chi_store, st)))
+        if ((rc = qc_reg_jets_fwd(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, chi_store, st)))
           return rc;
         if ((rc = after_launch())) return rc;
-      } else if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res,
-                                       d->circ_ws_dev, d->circ_ws_bytes, st))) return rc;
+      } else if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, cws, cws_bytes, st)))
+        return rc;
       // abar_res is written only by the adjoint sweep below: its head serves as cotangent scratch here
       if ((rc = qc_post(2, d->X_res_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_res_dev,
                         d->abar_res_dev, d->abar_res_dev + d->B_res, nullptr, nullptr, d->qbar_res_dev, d->part_dev,
                         d->part_stride, 0, d->B_res, 6, st))) return rc;
       if (use_reg(n)) {
-        if ((rc = qc_reg_jets_bwd(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
+        if ((rc = qc_reg_jets_bwd(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res,
                                   d->part_dev + L.oTh, d->part_stride, 0, d->B_res, chi_store, st))) return rc;
         if ((rc = after_launch())) return rc;
-      } else if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev,
-                                        d->part_dev + L.oTh, d->part_stride, 0, d->B_res, d->circ_ws_dev,
-                                        d->circ_ws_bytes, st))) return rc;
+      } else if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res,
+                                        d->part_dev + L.oTh, d->part_stride, 0, d->B_res, cws, cws_bytes, st))) return rc;
+      if (amp && (rc = qc_amp_backward(d->ajets_res_dev, ub_res, d->abar_res_dev, n, d->B_res, 6, st))) return rc;
       if ((rc = qc_pre_backward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->abar_res_dev, d->part_dev,
                                 d->part_stride, 0, d->B_res, 6, st))) return rc;
     }

@@ -98,6 +98,31 @@ __global__ void __launch_bounds__(256) k_hbm_init(const float* __restrict__ wd, 
   }
 }
 
+// amplitude encoding: chi[c][t][k] = (k < n ? ujets[c][k][p0+t] : 0), real
+template <int NCH>
+__global__ void __launch_bounds__(256) k_hbm_init_amp(const float* __restrict__ ujets, int64_t B, int64_t p0, int T, int n,
+                                                      Cplx* __restrict__ chi) {
+  const int64_t N = (int64_t)1 << n;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= (int64_t)T * N) return;
+  const int t = (int)(gid >> n);
+  const int64_t k = gid & (N - 1);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const float m = k < n ? ujets[((int64_t)c * n + k) * B + p0 + t] : 0.f;
+    chi[((size_t)c * T + t) * N + k] = {m, 0.f};
+  }
+}
+
+// amplitude encoding: abar[c][w][p] = 2 Re lam[c][t][w]
+template <int NCH>
+__global__ void k_hbm_abar_amp(const Cplx* __restrict__ lam, int T, int n, int64_t B, int64_t p0, float* __restrict__ abar) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NCH * T * n) return;
+  const int w = i % n, t = (i / n) % T, c = i / (n * T);
+  abar[((int64_t)c * n + w) * B + p0 + t] = 2.f * lam[((size_t)c * T + t) * ((size_t)1 << n) + w].re;
+}
+
 // ---------------------------------------------------------------- one gate over S statevectors
 __device__ __forceinline__ void coef_of(int op, float c, float s, bool t, float& ar, float& ai, float& br, float& bi) {
   ar = 1.f; ai = 0.f; br = 0.f; bi = 0.f;
@@ -863,12 +888,16 @@ static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* um
     const int T = (int)((B - p0) < 64 ? (B - p0) : 64);
     const int TA = T;                                   // layout stride = points of this tile
     if (backward) w.lam = w.chi + (size_t)NCH * T * N;  // lam directly behind chi: GRAD pairs v with v + nvec
-    hipLaunchKernelGGL((k_hbm_wiredata<NCH>), dim3(qc_ceil_div((int64_t)T * n, 256)), dim3(256), 0, st, ajets, B, p0, T, n, w.wd);
     const int64_t amps = (int64_t)TA * N;
-    if (backward)
-      hipLaunchKernelGGL((k_hbm_init<NCH, true>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n, w.chi, w.ser);
-    else
-      hipLaunchKernelGGL((k_hbm_init<NCH, false>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n, w.chi, w.ser);
+    if (pg->amplitude) {
+      hipLaunchKernelGGL((k_hbm_init_amp<NCH>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, ajets, B, p0, TA, n, w.chi);
+    } else {
+      hipLaunchKernelGGL((k_hbm_wiredata<NCH>), dim3(qc_ceil_div((int64_t)T * n, 256)), dim3(256), 0, st, ajets, B, p0, T, n, w.wd);
+      if (backward)
+        hipLaunchKernelGGL((k_hbm_init<NCH, true>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n, w.chi, w.ser);
+      else
+        hipLaunchKernelGGL((k_hbm_init<NCH, false>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n, w.chi, w.ser);
+    }
     const int64_t S = (int64_t)NCH * TA;
     if (staged) staged_forward(pg, trig_dev, umat, w, S, st);
     for (int g = 0; g < pg->n_gates && !staged; ++g) {
@@ -902,7 +931,10 @@ static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* um
                            n, gt, trig_dev, g, (float*)nullptr);
       }
     }
-    hipLaunchKernelGGL((k_hbm_abar<NCH>), dim3(n * T), dim3(256), 0, st, w.lam, w.ser, TA, n, B, p0, abar);
+    if (pg->amplitude)
+      hipLaunchKernelGGL((k_hbm_abar_amp<NCH>), dim3(qc_ceil_div((int64_t)NCH * T * n, 256)), dim3(256), 0, st, w.lam, TA, n, B, p0, abar);
+    else
+      hipLaunchKernelGGL((k_hbm_abar<NCH>), dim3(n * T), dim3(256), 0, st, w.lam, w.ser, TA, n, B, p0, abar);
     hipLaunchKernelGGL(k_hbm_store_row, dim3(qc_ceil_div(pg->n_params > 0 ? pg->n_params : 1, 256)), dim3(256), 0, st,
                        w.acc, pg->n_params, part + (row0 + p0 / 64) * part_stride);
   }

@@ -178,10 +178,19 @@ __device__ __forceinline__ void channel_series(float (&P0)[1 << N], float (&P1)[
   else qc_embed_series<N, 2>(P0, P1, P2, ca, sa, da, dda);
 }
 
-// Initial vector of channel `ch`.
+// Initial vector of channel `ch`.  amp != 0: amplitude encoding — `ajets` then holds the jets of the
+// (normalised, zero-padded) initial amplitudes themselves (qc_amp.hip): amplitude k = feature k, real.
 template <int N>
 __device__ __forceinline__ void build_channel(SV<N>& v, int ch, const float* __restrict__ ajets, int64_t B,
-                                              int64_t pc) {
+                                              int64_t pc, int amp) {
+  if (amp) {
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      v.re[k] = k < N ? ajets[((int64_t)ch * N + k) * B + pc] : 0.f;
+      v.im[k] = 0.f;
+    }
+    return;
+  }
   float P0[1 << N], P1[1 << N], P2[1 << N];
   channel_series<N>(P0, P1, P2, ch, ajets, B, pc);
   if (ch == 0) qc_phase_load<N>(v, P0);
@@ -201,18 +210,12 @@ template <class PG>
 __global__ void __launch_bounds__(256) k_value_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                    const float* __restrict__ umat, int n_gates,
                                                    const float* __restrict__ angles, float* __restrict__ expval,
-                                                   int64_t B) {
+                                                   int64_t B, int amp) {
   constexpr int N = PG::N;
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t pc = p < B ? p : B - 1;
-  float ca[N], sa[N], zero[N];
-#pragma unroll
-  for (int w = 0; w < N; ++w) zero[w] = 0.f;
-  load_sincos<N>(ca, sa, angles, B, pc);
-  float P0[1 << N], P1[1 << N], P2[1 << N];
-  qc_embed_series<N, 0>(P0, P1, P2, ca, sa, zero, zero);
   SV<N> v[1];
-  qc_phase_load<N>(v[0], P0);
+  build_channel<N>(v[0], 0, angles, B, pc, amp);
   PG::fwd(v, prog, trig, umat, n_gates);
   float t[1 << N], q[N];
 #pragma unroll
@@ -229,7 +232,7 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
                                                    const float* __restrict__ umat, int n_gates, int n_params,
                                                    const float* __restrict__ angles, const float* __restrict__ cot,
                                                    float* __restrict__ d_angles, float* __restrict__ part,
-                                                   int64_t part_stride, int64_t row0, int64_t B) {
+                                                   int64_t part_stride, int64_t row0, int64_t B, int amp) {
   constexpr int N = PG::N;
   extern __shared__ float smem[];  // [4 waves][n_params]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -239,16 +242,10 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = p < B;
   const int64_t pc = live ? p : B - 1;
-  float ca[N], sa[N], zero[N];
-#pragma unroll
-  for (int w = 0; w < N; ++w) zero[w] = 0.f;
-  load_sincos<N>(ca, sa, angles, B, pc);
-  float P0[1 << N], P1[1 << N], P2[1 << N];
-  qc_embed_series<N, 0>(P0, P1, P2, ca, sa, zero, zero);
   SV<N> cl[2];  // [0] = chi, [1] = lambda
   {
     SV<N> v[1];
-    qc_phase_load<N>(v[0], P0);
+    build_channel<N>(v[0], 0, angles, B, pc, amp);
     PG::fwd(v, prog, trig, umat, n_gates);
     cl[0] = v[0];
   }
@@ -265,7 +262,10 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
   }
   PG::bwd(cl, prog, trig, umat, n_gates, smem + wave * n_params, lane);
   float T[N];
-  {
+  if (amp) {   // d L / d(initial amplitude k) = 2 Re Lambda_k  (the initial amplitudes are real)
+#pragma unroll
+    for (int w = 0; w < N; ++w) T[w] = 2.f * cl[1].re[w];
+  } else {
     float Q0[1 << N], Q1[1 << N], Q2[1 << N];
     channel_series<N>(Q0, Q1, Q2, 0, qc_launder(angles), B, pc);
     qc_embed_ip<N>(T, cl[1], Q0);
@@ -286,7 +286,7 @@ template <class PG>
 __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates,
                                                   const float* __restrict__ ajets, float* __restrict__ qjets,
-                                                  int64_t B, float* __restrict__ chi_store) {
+                                                  int64_t B, float* __restrict__ chi_store, int amp) {
   constexpr int N = PG::N;
   constexpr int A2 = 2 << N;                 // floats per statevector
   __shared__ float s_chi0[A2 * 64];          // [amp*2+{re,im}][lane]
@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
   const int64_t pc = p < B ? p : B - 1;
 
   SV<N> v[1];
-  build_channel<N>(v[0], ch, ajets, B, pc);
+  build_channel<N>(v[0], ch, ajets, B, pc, amp);
   PG::fwd(v, prog, trig, umat, n_gates);
   if (chi_store != nullptr && p < B) {   // final states for the adjoint kernel of the same step: [6][A2][B]
 #pragma unroll
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
                                                   const float* __restrict__ ajets, const float* __restrict__ qbar,
                                                   float* __restrict__ abar, float* __restrict__ part,
                                                   int64_t part_stride, int64_t row0, int64_t B,
-                                                  const float* __restrict__ chi_store) {
+                                                  const float* __restrict__ chi_store, int amp) {
   constexpr int N = PG::N;
   constexpr int A2 = 2 << N;
   extern __shared__ float smem[];
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
     }
   } else {
     SV<N> v[1];
-    build_channel<N>(v[0], ch, ajets, B, pc);
+    build_channel<N>(v[0], ch, ajets, B, pc, amp);
     PG::fwd(v, prog, trig, umat, n_gates);
     cl[0] = v[0];
   }
@@ -439,48 +439,58 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
 
   PG::bwd(cl, prog, trig, umat, n_gates, s_acc + ch * n_params, lane);
 
-  // ---- cotangents of the angle jets: Im<Lambda| X_w |phi> against the embedding series, which is
-  // rebuilt here (exact, and cheaper than carrying 3 * 2^n registers through the sweep)
-  float P0[1 << N], P1[1 << N], P2[1 << N];
-  channel_series<N>(P0, P1, P2, ch, qc_launder(ajets), B, pc);
-  float* buf = s_chi + ch * 3 * N * 64;  // [3][N][64] per wave
-  float T[N];
-  if (ch == 0) {
-    qc_embed_ip<N>(T, cl[1], P0);
+  if (amp) {
+    // amplitude encoding: the channel's initial vector IS the input jet, so its cotangent is read off
+    // the swept lambda directly: d L / d u_c[k] = 2 Re Lambda_c[k] (no coupling between channels here)
+    if (live) {
 #pragma unroll
-    for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
-  } else if (ch <= 3) {
-    qc_embed_ip<N>(T, cl[1], P1);
-#pragma unroll
-    for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
-    qc_embed_ip<N>(T, cl[1], P0);
-#pragma unroll
-    for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = T[w];
+      for (int w = 0; w < N; ++w) abar[((int64_t)ch * N + w) * B + p] = 2.f * cl[1].re[w];
+    }
+    __syncthreads();
   } else {
-    qc_embed_ip<N>(T, cl[1], P2);
-#pragma unroll
-    for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
-    qc_embed_ip<N>(T, cl[1], P1);
-#pragma unroll
-    for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = 2.f * T[w];
-    qc_embed_ip<N>(T, cl[1], P0);
-#pragma unroll
-    for (int w = 0; w < N; ++w) buf[(2 * N + w) * 64 + lane] = T[w];
-  }
-  __syncthreads();
-  auto at = [&](int wv, int slot, int w) { return s_chi[((wv * 3 + slot) * N + w) * 64 + lane]; };
-#pragma unroll
-  for (int w = 0; w < N; ++w) {
-    float r;
-    if (ch == 0)
-      r = ((at(0, 0, w) + at(1, 0, w)) + (at(2, 0, w) + at(3, 0, w))) + (at(4, 0, w) + at(5, 0, w));
-    else if (ch == 1)
-      r = at(1, 1, w);
-    else if (ch <= 3)
-      r = at(ch, 1, w) + at(ch + 2, 1, w);
-    else
-      r = at(ch, 2, w);
-    if (live) abar[((int64_t)ch * N + w) * B + p] = r;
+    // ---- cotangents of the angle jets: Im<Lambda| X_w |phi> against the embedding series, which is
+    // rebuilt here (exact, and cheaper than carrying 3 * 2^n registers through the sweep)
+    float P0[1 << N], P1[1 << N], P2[1 << N];
+    channel_series<N>(P0, P1, P2, ch, qc_launder(ajets), B, pc);
+    float* buf = s_chi + ch * 3 * N * 64;  // [3][N][64] per wave
+    float T[N];
+    if (ch == 0) {
+      qc_embed_ip<N>(T, cl[1], P0);
+  #pragma unroll
+      for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
+    } else if (ch <= 3) {
+      qc_embed_ip<N>(T, cl[1], P1);
+  #pragma unroll
+      for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
+      qc_embed_ip<N>(T, cl[1], P0);
+  #pragma unroll
+      for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = T[w];
+    } else {
+      qc_embed_ip<N>(T, cl[1], P2);
+  #pragma unroll
+      for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
+      qc_embed_ip<N>(T, cl[1], P1);
+  #pragma unroll
+      for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = 2.f * T[w];
+      qc_embed_ip<N>(T, cl[1], P0);
+  #pragma unroll
+      for (int w = 0; w < N; ++w) buf[(2 * N + w) * 64 + lane] = T[w];
+    }
+    __syncthreads();
+    auto at = [&](int wv, int slot, int w) { return s_chi[((wv * 3 + slot) * N + w) * 64 + lane]; };
+  #pragma unroll
+    for (int w = 0; w < N; ++w) {
+      float r;
+      if (ch == 0)
+        r = ((at(0, 0, w) + at(1, 0, w)) + (at(2, 0, w) + at(3, 0, w))) + (at(4, 0, w) + at(5, 0, w));
+      else if (ch == 1)
+        r = at(1, 1, w);
+      else if (ch <= 3)
+        r = at(ch, 1, w) + at(ch + 2, 1, w);
+      else
+        r = at(ch, 2, w);
+      if (live) abar[((int64_t)ch * N + w) * B + p] = r;
+    }
   }
   for (int i = threadIdx.x; i < n_params; i += 384) {
     float s = 0.f;
@@ -507,7 +517,7 @@ struct RegLaunch {
   static int value_fwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* angles,
                        float* expval, int64_t B, hipStream_t st) {
     hipLaunchKernelGGL(k_value_fwd<PG>, dim3(qc_ceil_div(B, 256)), dim3(256), 0, st, pg->d_gates, trig, umat,
-                       pg->n_gates, angles, expval, B);
+                       pg->n_gates, angles, expval, B, pg->amplitude);
     return QC_OK;
   }
   static int value_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* angles,
@@ -515,13 +525,13 @@ struct RegLaunch {
                        int64_t B, hipStream_t st) {
     const size_t sh = (size_t)4 * pg->n_params * sizeof(float);
     hipLaunchKernelGGL(k_value_bwd<PG>, dim3(qc_ceil_div(B, 256)), dim3(256), sh, st, pg->d_gates, trig, umat,
-                       pg->n_gates, pg->n_params, angles, cot, d_angles, part, part_stride, row0, B);
+                       pg->n_gates, pg->n_params, angles, cot, d_angles, part, part_stride, row0, B, pg->amplitude);
     return QC_OK;
   }
   static int jets_fwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
                       float* qjets, int64_t B, float* chi_store, hipStream_t st) {
     hipLaunchKernelGGL(k_jets_fwd<PG>, dim3(qc_ceil_div(B, 64)), dim3(384), 0, st, pg->d_gates, trig, umat,
-                       pg->n_gates, ajets, qjets, B, chi_store);
+                       pg->n_gates, ajets, qjets, B, chi_store, pg->amplitude);
     return QC_OK;
   }
   static int jets_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
@@ -539,10 +549,10 @@ struct RegLaunch {
     }
     if (chi_store != nullptr)
       hipLaunchKernelGGL((k_jets_bwd<PG, true>), dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
-                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store);
+                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, pg->amplitude);
     else
       hipLaunchKernelGGL((k_jets_bwd<PG, false>), dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
-                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store);
+                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, pg->amplitude);
     return QC_OK;
   }
   static constexpr QcRegLaunchers table() { return {&value_fwd, &value_bwd, &jets_fwd, &jets_bwd}; }

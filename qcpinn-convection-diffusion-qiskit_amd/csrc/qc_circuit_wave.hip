@@ -307,6 +307,21 @@ __device__ __forceinline__ void phase_load(WV<LR> (&v)[NCH], const float (&P)[NC
   }
 }
 
+// amplitude encoding: the jets of the initial amplitudes are given (qc_amp.hip); amplitude k = feature k
+template <int LR, int NCH>
+__device__ __forceinline__ void amp_load(WV<LR> (&v)[NCH], const float* __restrict__ ujets, int64_t B, int64_t pc,
+                                         bool ok, const Grp& G) {
+#pragma unroll
+  for (int r = 0; r < (1 << LR); ++r) {
+    const int idx = amp_index<LR>(r, G.sub);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      v[c].re[r] = (ok && idx < G.n) ? ujets[((int64_t)c * G.n + idx) * B + pc] : 0.f;
+      v[c].im[r] = 0.f;
+    }
+  }
+}
+
 template <int LR, int K, bool ADJ, bool GRAD>
 __device__ __forceinline__ void run_program(WV<LR> (&v)[K], const QcGate* __restrict__ prog,
                                             const QcTrig* __restrict__ trig, const float* __restrict__ umat,
@@ -346,7 +361,7 @@ template <int LR, int NCH>
 __global__ void __launch_bounds__(256) k_wave_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates, int n,
                                                   const float* __restrict__ ajets, float* __restrict__ qjets,
-                                                  int64_t B) {
+                                                  int64_t B, int amp) {
   constexpr int R = 1 << LR;
   const Grp G = make_group(n);
   const int wave = threadIdx.x >> 6;
@@ -358,11 +373,15 @@ __global__ void __launch_bounds__(256) k_wave_fwd(const QcGate* __restrict__ pro
     const int64_t p = first + pass + slot;
     const bool ok = slot < ppw && p < B;
     const int64_t pc = ok ? p : 0;
-    const WireData mine = load_wire<NCH>(ajets, B, pc, G.sub, n, ok);
-    float P[NCH][R];
-    embed_series<LR, NCH>(P, mine, G);
     WV<LR> v[NCH];
-    phase_load<LR, NCH>(v, P, G);
+    if (amp) {
+      amp_load<LR, NCH>(v, ajets, B, pc, ok, G);
+    } else {
+      const WireData mine = load_wire<NCH>(ajets, B, pc, G.sub, n, ok);
+      float P[NCH][R];
+      embed_series<LR, NCH>(P, mine, G);
+      phase_load<LR, NCH>(v, P, G);
+    }
     run_program<LR, NCH, false, false>(v, prog, trig, umat, n_gates, G, nullptr);
     // per-amplitude weights of the bilinear forms
     float t[NCH][R];
@@ -397,7 +416,7 @@ __global__ void __launch_bounds__(256) k_wave_bwd(const QcGate* __restrict__ pro
                                                   const float* __restrict__ umat, int n_gates, int n_params, int n,
                                                   const float* __restrict__ ajets, const float* __restrict__ qbar,
                                                   float* __restrict__ abar, float* __restrict__ part,
-                                                  int64_t part_stride, int64_t row0, int64_t B) {
+                                                  int64_t part_stride, int64_t row0, int64_t B, int amp) {
   constexpr int R = 1 << LR;
   extern __shared__ float s_acc[];  // [4 waves][n_params]
   const Grp G = make_group(n);
@@ -412,13 +431,17 @@ __global__ void __launch_bounds__(256) k_wave_bwd(const QcGate* __restrict__ pro
     const int64_t p = first + pass + slot;
     const bool ok = slot < ppw && p < B;
     const int64_t pc = ok ? p : 0;
-    const WireData mine = load_wire<NCH>(ajets, B, pc, G.sub, n, ok);
     float P[NCH][R];
-    embed_series<LR, NCH>(P, mine, G);
     WV<LR> v[2 * NCH];  // [0,NCH) chi, [NCH,2NCH) lam
     {
       WV<LR> f[NCH];
-      phase_load<LR, NCH>(f, P, G);
+      if (amp) {
+        amp_load<LR, NCH>(f, ajets, B, pc, ok, G);
+      } else {
+        const WireData mine = load_wire<NCH>(ajets, B, pc, G.sub, n, ok);
+        embed_series<LR, NCH>(P, mine, G);
+        phase_load<LR, NCH>(f, P, G);
+      }
       run_program<LR, NCH, false, false>(f, prog, trig, umat, n_gates, G, nullptr);
 #pragma unroll
       for (int c = 0; c < NCH; ++c) v[c] = f[c];
@@ -460,6 +483,16 @@ __global__ void __launch_bounds__(256) k_wave_bwd(const QcGate* __restrict__ pro
     }
     run_program<LR, 2 * NCH, true, true>(v, prog, trig, umat, n_gates, G, s_acc + wave * n_params);
 
+    if (amp) {   // d L / d(initial amplitude k of channel c) = 2 Re Lambda_c[k], k < n
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int idx = amp_index<LR>(r, G.sub);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+          if (ok && idx < n) abar[((int64_t)c * n + idx) * B + p] = 2.f * v[NCH + c].re[r];
+      }
+      continue;
+    }
     // ---- cotangents of the angle jets: T(Lam, phi)[w] = Im <Lam| X_w |phi>, phi = (-i)^pop * P
     for (int w = 0; w < n; ++w) {
       const int b = n - 1 - w;
@@ -538,7 +571,7 @@ int qc_wave_value_fwd(const qc_program* pg, const QcTrig* trig, const float* uma
                       float* expval, int64_t B, hipStream_t st) {
   const int grid = qc_ceil_div(B, 64);
 #define CALL(LRR) \
-  hipLaunchKernelGGL((k_wave_fwd<LRR, 1>), dim3(grid), dim3(256), 0, st, pg->d_gates, trig, umat, pg->n_gates, pg->n_qubits, angles, expval, B);
+  hipLaunchKernelGGL((k_wave_fwd<LRR, 1>), dim3(grid), dim3(256), 0, st, pg->d_gates, trig, umat, pg->n_gates, pg->n_qubits, angles, expval, B, pg->amplitude);
   QC_WAVE_DISPATCH(pg->n_qubits, CALL)
 #undef CALL
   return QC_OK;
@@ -548,7 +581,7 @@ int qc_wave_jets_fwd(const qc_program* pg, const QcTrig* trig, const float* umat
                      int64_t B, hipStream_t st) {
   const int grid = qc_ceil_div(B, 64);
 #define CALL(LRR) \
-  hipLaunchKernelGGL((k_wave_fwd<LRR, 6>), dim3(grid), dim3(256), 0, st, pg->d_gates, trig, umat, pg->n_gates, pg->n_qubits, ajets, qjets, B);
+  hipLaunchKernelGGL((k_wave_fwd<LRR, 6>), dim3(grid), dim3(256), 0, st, pg->d_gates, trig, umat, pg->n_gates, pg->n_qubits, ajets, qjets, B, pg->amplitude);
   QC_WAVE_DISPATCH(pg->n_qubits, CALL)
 #undef CALL
   return QC_OK;
@@ -561,7 +594,7 @@ int qc_wave_value_bwd(const qc_program* pg, const QcTrig* trig, const float* uma
   const size_t sh = (size_t)4 * pg->n_params * sizeof(float);
 #define CALL(LRR)                                                                                               \
   hipLaunchKernelGGL((k_wave_bwd<LRR, 1>), dim3(grid), dim3(256), sh, st, pg->d_gates, trig, umat, pg->n_gates, \
-                     pg->n_params, pg->n_qubits, angles, cot, d_angles, part, part_stride, row0, B);
+                     pg->n_params, pg->n_qubits, angles, cot, d_angles, part, part_stride, row0, B, pg->amplitude);
   QC_WAVE_DISPATCH(pg->n_qubits, CALL)
 #undef CALL
   return QC_OK;
@@ -574,7 +607,7 @@ int qc_wave_jets_bwd(const qc_program* pg, const QcTrig* trig, const float* umat
   const size_t sh = (size_t)4 * pg->n_params * sizeof(float);
 #define CALL(LRR)                                                                                               \
   hipLaunchKernelGGL((k_wave_bwd<LRR, 6>), dim3(grid), dim3(256), sh, st, pg->d_gates, trig, umat, pg->n_gates, \
-                     pg->n_params, pg->n_qubits, ajets, qbar, abar, part, part_stride, row0, B);
+                     pg->n_params, pg->n_qubits, ajets, qbar, abar, part, part_stride, row0, B, pg->amplitude);
   QC_WAVE_DISPATCH(pg->n_qubits, CALL)
 #undef CALL
   return QC_OK;

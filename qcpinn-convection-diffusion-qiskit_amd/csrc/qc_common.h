@@ -37,6 +37,7 @@ struct qc_program {
   QcGate* d_gates;  // device
   QcGate* h_gates;  // host copy
   void* hbm_plan;   // QcHbmPlan* for n >= 9 (staged execution), else null
+  int amplitude;    // 1: amplitude encoding (initial state given directly), 0: RX angle embedding
 };
 
 // Channel numbering of the derivative ("jet") channels carried through the network:

@@ -91,3 +91,5 @@ int qc_hbm_forward(const qc_program* pg, const QcTrig* trig, const float* umat, 
 int qc_hbm_backward(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, const float* qbar,
                     float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, void* ws,
                     size_t ws_bytes, hipStream_t);
+int qc_amp_fwd_launch(const float* a, float* u, int n, int64_t B, int nch, hipStream_t);
+int qc_amp_bwd_launch(const float* a, const float* ub, float* ab, int n, int64_t B, int nch, hipStream_t);

@@ -48,7 +48,8 @@ def param_layout(H: int, n: int, n_theta: int) -> Dict[str, Tuple[int, Tuple[int
 class Circuit:
     """A device-resident gate program + its per-gate trig table and fixed-unitary table."""
 
-    def __init__(self, program: GateProgram, haar: Optional[np.ndarray], device: torch.device):
+    def __init__(self, program: GateProgram, haar: Optional[np.ndarray], device: torch.device,
+                 amplitude: bool = False):
         if device.type != "cuda":
             raise L.QcError("the HIP kernels need a GPU device (torch device type 'cuda' on ROCm); "
                             "there is no CPU fallback")
@@ -62,6 +63,9 @@ class Circuit:
         with torch.cuda.device(device):
             L.check(self.lib.qc_program_create(rows.ctypes.data_as(C.c_void_p), program.n_gates, self.n,
                                                self.n_params, C.byref(self.handle)), "qc_program_create")
+        self.amplitude = bool(amplitude)
+        if self.amplitude:
+            L.check(self.lib.qc_program_set_encoding(self.handle, 1), "qc_program_set_encoding")
         self.trig = torch.zeros(2 * program.n_gates, dtype=torch.float32, device=device)
         self.umat = None
         if program.use_haar:
@@ -96,8 +100,23 @@ class Circuit:
         L.check(self.lib.qc_prepare_gates(self.handle, theta.data_ptr(), self.trig.data_ptr(),
                                           _stream(self.device)), "qc_prepare_gates")
 
+    # -- amplitude encoding: features -> jets of the normalised initial amplitudes, and back
+    def _amp_fwd(self, a: torch.Tensor, nch: int) -> torch.Tensor:
+        u = torch.empty_like(a)
+        L.check(self.lib.qc_amp_forward(a.data_ptr(), u.data_ptr(), self.n, a.shape[-1], nch, _stream(self.device)),
+                "qc_amp_forward")
+        return u
+
+    def _amp_bwd(self, a: torch.Tensor, ubar: torch.Tensor, nch: int) -> torch.Tensor:
+        ab = torch.empty_like(a)
+        L.check(self.lib.qc_amp_backward(a.data_ptr(), ubar.data_ptr(), ab.data_ptr(), self.n, a.shape[-1], nch,
+                                         _stream(self.device)), "qc_amp_backward")
+        return ab
+
     def forward_expval(self, angles_nB: torch.Tensor) -> torch.Tensor:
         a = _need(angles_nB, self.device, "angles")
+        if self.amplitude:
+            a = self._amp_fwd(a, 1)
         B = a.shape[1]
         out = torch.empty_like(a)
         wp, wb = self.workspace(1, False)
@@ -106,7 +125,9 @@ class Circuit:
         return out
 
     def backward_expval(self, angles_nB: torch.Tensor, cot_nB: torch.Tensor):
-        a = _need(angles_nB, self.device, "angles")
+        a = a_in = _need(angles_nB, self.device, "angles")
+        if self.amplitude:
+            a = self._amp_fwd(a_in, 1)
         g = _need(cot_nB, self.device, "cotangent")
         B = a.shape[1]
         rows = (B + 63) // 64
@@ -120,10 +141,14 @@ class Circuit:
                 "qc_backward_expval")
         d_theta = torch.empty(P, dtype=torch.float32, device=self.device)
         L.check(self.lib.qc_reduce_rows(part.data_ptr(), rows, P, P, d_theta.data_ptr(), st), "qc_reduce_rows")
+        if self.amplitude:
+            d_angles = self._amp_bwd(a_in, d_angles, 1)
         return d_angles, d_theta[: self.n_params]
 
     def forward_jets(self, ajets: torch.Tensor) -> torch.Tensor:
         a = _need(ajets, self.device, "angle jets")            # (6, n, B)
+        if self.amplitude:
+            a = self._amp_fwd(a, NCH)
         B = a.shape[2]
         out = torch.empty_like(a)
         wp, wb = self.workspace(NCH, False)
@@ -132,7 +157,9 @@ class Circuit:
         return out
 
     def backward_jets(self, ajets: torch.Tensor, qbar: torch.Tensor):
-        a = _need(ajets, self.device, "angle jets")
+        a = a_in = _need(ajets, self.device, "angle jets")
+        if self.amplitude:
+            a = self._amp_fwd(a_in, NCH)
         g = _need(qbar, self.device, "cotangent jets")
         B = a.shape[2]
         rows = (B + 63) // 64
@@ -146,6 +173,8 @@ class Circuit:
                 "qc_backward_jets")
         d_theta = torch.empty(P, dtype=torch.float32, device=self.device)
         L.check(self.lib.qc_reduce_rows(part.data_ptr(), rows, P, P, d_theta.data_ptr(), st), "qc_reduce_rows")
+        if self.amplitude:
+            abar = self._amp_bwd(a_in, abar, NCH)
         return abar, d_theta[: self.n_params]
 
 
@@ -227,14 +256,17 @@ class SolverEngine:
         th = part.data_ptr() + 4 * self.theta_off
         c = self.circuit
         wp, wb = c.workspace(nch, True)
+        cin = c._amp_fwd(ajets, nch) if c.amplitude else ajets
         if nch == 1:
-            L.check(self.lib.qc_backward_expval(c.handle, c.trig.data_ptr(), _ptr(c.umat), ajets.data_ptr(),
+            L.check(self.lib.qc_backward_expval(c.handle, c.trig.data_ptr(), _ptr(c.umat), cin.data_ptr(),
                                                 qbar.data_ptr(), abar.data_ptr(), th, self.NP, 0, B, wp, wb, st),
                     "qc_backward_expval")
         else:
-            L.check(self.lib.qc_backward_jets(c.handle, c.trig.data_ptr(), _ptr(c.umat), ajets.data_ptr(),
+            L.check(self.lib.qc_backward_jets(c.handle, c.trig.data_ptr(), _ptr(c.umat), cin.data_ptr(),
                                               qbar.data_ptr(), abar.data_ptr(), th, self.NP, 0, B, wp, wb, st),
                     "qc_backward_jets")
+        if c.amplitude:
+            abar = c._amp_bwd(ajets, abar, nch)
         L.check(self.lib.qc_pre_backward(X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
                                          abar.data_ptr(), part.data_ptr(), self.NP, 0, B, nch, st),
                 "qc_pre_backward")
@@ -329,7 +361,7 @@ class FusedStep:
         d.flat_dev = self.flat_grad.data_ptr()
         d.pde = eng._pde(max(g_res, 1), max(g_ic, 1), max(g_bc, 1), n_ic)
         d.hyper = opt.hyper
-        need = int(eng.lib.qc_step_workspace_bytes(c.handle, B_res))
+        need = int(eng.lib.qc_step_workspace_bytes(c.handle, B_res, B_val))
         self.step_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
         d.circ_ws_dev, d.circ_ws_bytes = (self.step_ws.data_ptr(), need) if need else (None, 0)
         d.n_ic = n_ic

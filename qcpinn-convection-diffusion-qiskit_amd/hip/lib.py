@@ -20,7 +20,8 @@ QC_PHASE_SAMPLE = 4
 # every symbol include/qcpinn_hip.h declares
 EXPORTS = (
     "qc_version", "qc_error_string", "qc_last_hip_error", "qc_program_create", "qc_program_destroy",
-    "qc_trig_bytes", "qc_prepare_gates", "qc_circuit_workspace_bytes", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
+    "qc_trig_bytes", "qc_program_set_encoding", "qc_amp_forward", "qc_amp_backward", "qc_prepare_gates",
+    "qc_circuit_workspace_bytes", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_forward_jets_keep", "qc_backward_jets_kept", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
     "qc_sample_collocation", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
 )
@@ -103,7 +104,10 @@ def load() -> C.CDLL:
     lib.qc_adam_step.argtypes = [fp, i32, fp, fp, fp, vp, C.POINTER(QcOptHyper), fp, i32, vp, i32, vp, vp]
     lib.qc_sample_collocation.argtypes = [fp, i64, i64, fp, i64, i64, i64, i64, C.c_uint64, C.c_uint64, vp]
     lib.qc_step_workspace_bytes.restype = C.c_size_t
-    lib.qc_step_workspace_bytes.argtypes = [vp, i64]
+    lib.qc_step_workspace_bytes.argtypes = [vp, i64, i64]
+    lib.qc_program_set_encoding.argtypes = [vp, i32]
+    lib.qc_amp_forward.argtypes = [fp, fp, i32, i64, i32, vp]
+    lib.qc_amp_backward.argtypes = [fp, fp, fp, i32, i64, i32, vp]
     lib.qc_fused_pinn_residual_step.argtypes = [C.POINTER(QcStepDesc), i32, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)

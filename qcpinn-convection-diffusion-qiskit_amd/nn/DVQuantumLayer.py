@@ -8,8 +8,12 @@ What differs is only where the arithmetic runs: instead of a PennyLane ``default
 evaluated by the HIP statevector kernels (``csrc/qc_circuit_*.hip``) through ``libqcpinn_hip.so``;
 its backward is the HIP adjoint sweep.  There is no CPU path: a CPU input raises.
 
+``encoding == "amplitude"`` selects AmplitudeEmbedding(normalize=True, pad_with=0.0) (:177-180): the n
+features, zero-padded and L2-normalised, are the initial statevector; anything else is the RX angle
+embedding (:182), as in the reference.
+
 Out of scope, by design: IBM Runtime devices / shot-based execution
-(``use_ibm_hardware=True``) and amplitude encoding are refused with an explicit error.
+(``use_ibm_hardware=True``) are refused with an explicit error.
 """
 from __future__ import annotations
 
@@ -74,8 +78,6 @@ class DVQuantumLayer(nn.Module):
             raise NotImplementedError(
                 "use_ibm_hardware=True selects the IBM Runtime / shot-based branch of the reference, which is "
                 "outside the MI355X simulator path; set use_ibm_hardware=False (the analytic simulator branch)")
-        if self.encoding == "amplitude":
-            raise NotImplementedError("amplitude encoding is not built yet; use angle encoding (encoding != 'amplitude')")
         self.use_batch_processing = True
         self.dev = "hip.statevector"
         # lowered once; raises the same IndexError the reference hits for over-indexed ansaetze
@@ -91,7 +93,8 @@ class DVQuantumLayer(nn.Module):
                           f"got an input on {device}")
         key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
         if key not in self._circuits:
-            self._circuits[key] = _engine.Circuit(self.program, self._haar, torch.device(*key))
+            self._circuits[key] = _engine.Circuit(self.program, self._haar, torch.device(*key),
+                                                  amplitude=(self.encoding == "amplitude"))
         return self._circuits[key]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -106,7 +109,8 @@ class DVQuantumLayer(nn.Module):
 
     def describe(self) -> str:
         names = circuits.OP_NAMES
-        lines = [f"AngleEmbedding RX on wires 0..{self.num_qubits - 1}"]
+        lines = ["AmplitudeEmbedding(normalize, pad 0)" if self.encoding == "amplitude"
+                 else f"AngleEmbedding RX on wires 0..{self.num_qubits - 1}"]
         for g in self.program.gates:
             w = f"[{g.a}]" if g.b < 0 else f"[{g.a},{g.b}]"
             lines.append(f"{names[g.op]}{w}" + (f" p{g.slot}" if g.op in circuits.PARAMETRIC else ""))

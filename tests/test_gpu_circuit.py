@@ -148,3 +148,47 @@ def test_hbm_per_gate_path_agrees_with_staged_path():
                         "-x", "-k", sel], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "4 passed" in r.stdout
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", [("cascade", 4, 1, 1, 70), ("layered", 5, 1, 1, 9), ("layered", 6, 1, 1, 5),
+                                              ("layered", 8, 1, 1, 3), ("cascade", 9, 1, 1, 3), ("cascade", 2, 1, None, 6)])
+def test_amplitude_encoding_matches_oracle(ans, n, L, seed, B, gpu_device):
+    """encoding="amplitude" (AmplitudeEmbedding, nn/DVQuantumLayer.py:177-180): <Z>, its vjp, the six
+    derivative channels and their cotangents, in all three kernel families."""
+    g = torch.Generator().manual_seed(31 + n + B)
+    circuits = pkg("circuits")
+    engine = pkg("hip.engine")
+    P = circuits.params_per_layer(ans, n)
+    use_haar = seed is not None and n >= 4
+    prog = circuits.build_program(ans, n, L, use_haar)
+    haar_np = circuits.haar_unitaries(seed, seed + 1) if use_haar else None
+    haar = sv.haar_pair(seed, seed + 1) if use_haar else None
+    circ = engine.Circuit(prog, haar_np, gpu_device, amplitude=True)
+    params = torch.randn(L, P, generator=g) * 0.8
+    x = torch.randn(B, n, generator=g) + 0.3
+    cot = torch.randn(n, B, generator=g)
+    xo = x.double().requires_grad_(True)
+    po = params.double().requires_grad_(True)
+    q = sv.circuit_expvals(xo, po, ans, n, haar, "amplitude")
+    (q * cot.double()).sum().backward()
+    circ.prepare(params.to(gpu_device))
+    ang = x.t().contiguous().to(gpu_device)
+    qh = circ.forward_expval(ang)
+    assert (qh.cpu().double() - q.detach()).abs().max() < TOL_Z
+    d_ang, d_theta = circ.backward_expval(ang, cot.to(gpu_device))
+    assert (d_ang.t().cpu().double() - xo.grad).abs().max() < 2e-5 * max(1.0, xo.grad.abs().max().item())
+    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 2e-5 * max(1.0, po.grad.abs().max().item()) * np.sqrt(B)
+    # derivative channels
+    ajets = torch.randn(6, n, B, generator=g) * 0.9
+    ajets[0] += 0.3
+    w = torch.randn(6, n, B, generator=g)
+    ao = ajets.double().requires_grad_(True)
+    po2 = params.double().requires_grad_(True)
+    qo = ojets.qjets_from_ajets(ao, po2, ans, n, haar, "amplitude")
+    (qo * w.double()).sum().backward()
+    aj = ajets.to(gpu_device)
+    qj = circ.forward_jets(aj)
+    assert (qj.cpu().double() - qo.detach()).abs().max() < 2e-5 * max(1.0, qo.detach().abs().max().item())
+    abar, d_theta = circ.backward_jets(aj, w.to(gpu_device))
+    assert (abar.cpu().double() - ao.grad).abs().max() < 5e-5 * max(1.0, ao.grad.abs().max().item())
+    assert (d_theta.cpu().double() - po2.grad.reshape(-1)).abs().max() < 5e-5 * max(1.0, po2.grad.abs().max().item())

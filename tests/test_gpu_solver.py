@@ -239,3 +239,24 @@ def test_grid_evaluation_and_checkpoint_roundtrip(gpu_device, tmp_path):
     m2.quantum_layer.load_state_dict(st["quantum_layer"])
     out2 = ev.evaluate(m2, 20)
     assert out2["error_u"] == out["error_u"] and out2["error_f"] == out["error_f"]
+
+
+@pytest.mark.parametrize("over", [{"encoding": "amplitude"}, {"encoding": "amplitude", "num_qubits": 6, "q_ansatz": "layered"}])
+def test_amplitude_encoding_training_matches_oracle(over, gpu_device, tmp_path):
+    """Three fused training steps with encoding="amplitude" vs the CPU oracle running the reference loop."""
+    from oracle import solver as osol
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    trainer = pkg("trainer.diffusion_train")
+    args = base_args(epochs=2, **over)
+    torch.manual_seed(1)
+    model = Solver(args, Log(tmp_path), device=gpu_device)
+    torch.manual_seed(1)
+    ref = osol.OracleSolver(args, device=torch.device("cpu"))
+    torch.manual_seed(5)
+    batches = [(osol.sample_box(osol.BOX_IC, 5), osol.sample_box(osol.BOX_BC1, 5), osol.sample_box(osol.BOX_DOM, 16))
+               for _ in range(3)]
+    trainer.train(model, batch_size=16, batches=batches)
+    for b in batches:
+        osol.train_step(ref, 16, b)
+    got, want = np.array(model.loss_history), np.array(ref.loss_history)
+    assert np.abs(got - want).max() < 1e-4 * max(1.0, np.abs(want).max()), (got, want)

@@ -158,3 +158,25 @@ def test_haar_unitaries_match_fixture_and_are_unitary():
         for k in range(2):
             assert np.abs(U[k] @ U[k].conj().T - np.eye(4)).max() < 1e-12
     assert abs(z["seed1"][0, 0] - (0.6793174318473825 - 0.07211119614799695j)) < 1e-13   # SURVEY §8c value
+
+
+def test_amplitude_embedding_conventions():
+    """AmplitudeEmbedding(normalize=True, pad_with=0): features fill amplitudes 0..n-1 of the index with
+    wire 0 as MSB.  x = e_0 is |0...0>, i.e. the angle embedding at zero angles; scaling x changes nothing."""
+    n, ans = 4, "cascade"
+    g = torch.Generator().manual_seed(2)
+    params = torch.randn(1, 12, generator=g, dtype=torch.float64)
+    haar = sv.haar_pair(1, 2)
+    e0 = torch.tensor([[1.0, 0.0, 0.0, 0.0]], dtype=torch.float64)
+    qa = sv.circuit_expvals(e0, params, ans, n, haar, "amplitude")
+    qz = sv.circuit_expvals(torch.zeros(1, n, dtype=torch.float64), params, ans, n, haar, "angle")
+    assert (qa - qz).abs().max() < 1e-14
+    x = torch.randn(3, n, generator=g, dtype=torch.float64)
+    q1 = sv.circuit_expvals(x, params, ans, n, haar, "amplitude")
+    q2 = sv.circuit_expvals(3.7 * x, params, ans, n, haar, "amplitude")
+    assert (q1 - q2).abs().max() < 1e-13
+    # feature 1 lands on amplitude index 1 = |0001>: only the LAST wire is flipped before the ansatz
+    sim = sv.Simulator(2, 1)
+    q = sv.circuit_expvals(torch.tensor([[0.0, 1.0]], dtype=torch.float64), torch.zeros(1, 6, dtype=torch.float64), "cascade", 2, None, "amplitude")
+    assert abs(q[0, 0].item() - 1.0) < 1e-14          # wire 0 still |0>; wire 1 = H|1> -> <Z> = 0
+    assert abs(q[1, 0].item()) < 1e-14
