@@ -117,6 +117,12 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p) : -1;
   p->hbm_plan = nullptr;
   p->amplitude = 0;
+  p->lead_rx = n_gates >= n_qubits ? 1 : 0;   // RX(p_w) right after the embedding RX(a_w), wire by wire, distinct slots
+  for (int g = 0; g < n_qubits && p->lead_rx; ++g)
+    if (h[g].op != QC_RX || h[g].ba != n_qubits - 1 - g || h[g].slot < 0) p->lead_rx = 0;
+  for (int g = 0; g < n_qubits && p->lead_rx; ++g)
+    for (int k = 0; k < g; ++k)
+      if (h[k].slot == h[g].slot) p->lead_rx = 0;
   hipError_t e = hipMalloc((void**)&p->d_gates, sizeof(QcGate) * n_gates);
   if (e == hipSuccess) e = hipMemcpy(p->d_gates, h, sizeof(QcGate) * n_gates, hipMemcpyHostToDevice);
   if (e != hipSuccess) {

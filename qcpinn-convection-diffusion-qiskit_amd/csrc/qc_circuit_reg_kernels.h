@@ -19,6 +19,8 @@
 #include "qc_gates.h"
 #include "qc_internal.h"
 
+#include <stdlib.h>
+
 #include <utility>
 
 namespace {
@@ -30,8 +32,8 @@ struct DynProg {
   static constexpr int N = NQ;
   __device__ static __forceinline__ void fwd(SV<NQ> (&v)[1], const QcGate* __restrict__ prog,
                                              const QcTrig* __restrict__ trig, const float* __restrict__ umat,
-                                             int n_gates) {
-    for (int g = 0; g < n_gates; ++g) {
+                                             int n_gates, int absorb) {
+    for (int g = absorb ? NQ : 0; g < n_gates; ++g) {
       const QcGate gt = prog[g];
       const QcTrig tr = trig[g];
       qc_apply_gate<NQ, 1, false>(v, gt, tr.c, tr.s, umat);
@@ -41,8 +43,9 @@ struct DynProg {
   // acc_wave[slot] (LDS, one row per wave), then un-applies the gate on both.
   __device__ static __forceinline__ void bwd(SV<NQ> (&cl)[2], const QcGate* __restrict__ prog,
                                              const QcTrig* __restrict__ trig, const float* __restrict__ umat,
-                                             int n_gates, float* __restrict__ acc_wave, int lane) {
-    for (int g = n_gates - 1; g >= 0; --g) {
+                                             int n_gates, float* __restrict__ acc_wave, int lane, int absorb) {
+    const int g_first = absorb ? NQ : 0;
+    for (int g = n_gates - 1; g >= g_first; --g) {
       const QcGate gt = prog[g];
       const QcTrig tr = trig[g];
       if (gt.op != QC_U4 && gt.slot >= 0) {
@@ -93,8 +96,11 @@ struct StatProg {
   static constexpr int N = SP::N;
   template <int I>
   __device__ static __forceinline__ void fwd_one(SV<N> (&v)[1], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat) {
+                                                 const float* __restrict__ umat, int absorb) {
     constexpr SGate g = SP::g[I];
+    if constexpr (I < N) {
+      if (absorb) return;   // leading RX layer folded into the embedding angles
+    }
     float c = 1.f, s = 0.f;
     if constexpr (g.op != QC_U4 && g.slot >= 0) {
       const QcTrig tr = trig[I];
@@ -106,21 +112,26 @@ struct StatProg {
   }
   template <int... Is>
   __device__ static __forceinline__ void fwd_all(SV<N> (&v)[1], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, std::integer_sequence<int, Is...>) {
-    (fwd_one<Is>(v, trig, umat), ...);
+                                                 const float* __restrict__ umat, int absorb,
+                                                 std::integer_sequence<int, Is...>) {
+    (fwd_one<Is>(v, trig, umat, absorb), ...);
   }
   __device__ static __forceinline__ void fwd(SV<N> (&v)[1], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
-                                             const float* __restrict__ umat, int) {
-    fwd_all(v, trig, umat, std::make_integer_sequence<int, SP::G>{});
+                                             const float* __restrict__ umat, int, int absorb) {
+    fwd_all(v, trig, umat, absorb, std::make_integer_sequence<int, SP::G>{});
   }
   // Reverse sweep.  Parameter slots are compile-time constants here, so the wave totals of the
   // gradient terms stay in registers (gacc[slot], valid in lane 63) and reach LDS once, after the
   // sweep, instead of one LDS read-modify-write round trip per gate.
   template <int J>
   __device__ static __forceinline__ void bwd_one(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, float (&gacc)[SP::P > 0 ? SP::P : 1]) {
+                                                 const float* __restrict__ umat, float (&gacc)[SP::P > 0 ? SP::P : 1],
+                                                 int absorb) {
     constexpr int I = SP::G - 1 - J;
     constexpr SGate g = SP::g[I];
+    if constexpr (I < N) {
+      if (absorb) return;
+    }
     float c = 1.f, s = 0.f;
     if constexpr (g.op != QC_U4 && g.slot >= 0) {
       const QcTrig tr = trig[I];
@@ -134,16 +145,16 @@ struct StatProg {
   template <int... Js>
   __device__ static __forceinline__ void bwd_all(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
                                                  const float* __restrict__ umat, float (&gacc)[SP::P > 0 ? SP::P : 1],
-                                                 std::integer_sequence<int, Js...>) {
-    (bwd_one<Js>(cl, trig, umat, gacc), ...);
+                                                 int absorb, std::integer_sequence<int, Js...>) {
+    (bwd_one<Js>(cl, trig, umat, gacc, absorb), ...);
   }
   __device__ static __forceinline__ void bwd(SV<N> (&cl)[2], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
                                              const float* __restrict__ umat, int, float* __restrict__ acc_wave,
-                                             int lane) {
+                                             int lane, int absorb) {
     float gacc[SP::P > 0 ? SP::P : 1];
 #pragma unroll
     for (int k = 0; k < (SP::P > 0 ? SP::P : 1); ++k) gacc[k] = 0.f;
-    bwd_all(cl, trig, umat, gacc, std::make_integer_sequence<int, SP::G>{});
+    bwd_all(cl, trig, umat, gacc, absorb, std::make_integer_sequence<int, SP::G>{});
 #pragma unroll
     for (int k = 0; k < SP::P; ++k)
       if (lane == 63) acc_wave[k] += gacc[k];   // lane 63 holds the wave totals
@@ -152,10 +163,11 @@ struct StatProg {
 
 template <int N>
 __device__ __forceinline__ void load_sincos(float (&ca)[N], float (&sa)[N], const float* __restrict__ a,
-                                            int64_t B, int64_t p) {
+                                            int64_t B, int64_t p, const QcTrig* __restrict__ trig, int absorb) {
 #pragma unroll
   for (int w = 0; w < N; ++w) {
-    const float h = 0.5f * a[(int64_t)w * B + p];
+    // absorb: gate w is RX(theta_w) on wire w, applied right after RX(a_w): one rotation by a_w + theta_w
+    const float h = 0.5f * (a[(int64_t)w * B + p] + (absorb ? trig[w].th : 0.f));
     sincosf(h, &sa[w], &ca[w]);
   }
 }
@@ -164,9 +176,10 @@ __device__ __forceinline__ void load_sincos(float (&ca)[N], float (&sa)[N], cons
 // P2 = d2 phi (only as far as the channel needs).
 template <int N>
 __device__ __forceinline__ void channel_series(float (&P0)[1 << N], float (&P1)[1 << N], float (&P2)[1 << N],
-                                               int ch, const float* __restrict__ ajets, int64_t B, int64_t pc) {
+                                               int ch, const float* __restrict__ ajets, int64_t B, int64_t pc,
+                                               const QcTrig* __restrict__ trig, int absorb) {
   float ca[N], sa[N], da[N], dda[N];
-  load_sincos<N>(ca, sa, ajets, B, pc);
+  load_sincos<N>(ca, sa, ajets, B, pc, trig, absorb);
   const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);  // channel holding the first derivative
 #pragma unroll
   for (int w = 0; w < N; ++w) {
@@ -182,7 +195,7 @@ __device__ __forceinline__ void channel_series(float (&P0)[1 << N], float (&P1)[
 // (normalised, zero-padded) initial amplitudes themselves (qc_amp.hip): amplitude k = feature k, real.
 template <int N>
 __device__ __forceinline__ void build_channel(SV<N>& v, int ch, const float* __restrict__ ajets, int64_t B,
-                                              int64_t pc, int amp) {
+                                              int64_t pc, int amp, const QcTrig* __restrict__ trig, int absorb) {
   if (amp) {
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
@@ -192,7 +205,7 @@ __device__ __forceinline__ void build_channel(SV<N>& v, int ch, const float* __r
     return;
   }
   float P0[1 << N], P1[1 << N], P2[1 << N];
-  channel_series<N>(P0, P1, P2, ch, ajets, B, pc);
+  channel_series<N>(P0, P1, P2, ch, ajets, B, pc, trig, absorb);
   if (ch == 0) qc_phase_load<N>(v, P0);
   else if (ch <= 3) qc_phase_load<N>(v, P1);
   else qc_phase_load<N>(v, P2);
@@ -215,8 +228,8 @@ __global__ void __launch_bounds__(256) k_value_fwd(const QcGate* __restrict__ pr
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t pc = p < B ? p : B - 1;
   SV<N> v[1];
-  build_channel<N>(v[0], 0, angles, B, pc, amp);
-  PG::fwd(v, prog, trig, umat, n_gates);
+  build_channel<N>(v[0], 0, angles, B, pc, amp & 1, trig, amp >> 1);
+  PG::fwd(v, prog, trig, umat, n_gates, amp >> 1);
   float t[1 << N], q[N];
 #pragma unroll
   for (int k = 0; k < (1 << N); ++k) t[k] = v[0].re[k] * v[0].re[k] + v[0].im[k] * v[0].im[k];
@@ -245,8 +258,8 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
   SV<N> cl[2];  // [0] = chi, [1] = lambda
   {
     SV<N> v[1];
-    build_channel<N>(v[0], 0, angles, B, pc, amp);
-    PG::fwd(v, prog, trig, umat, n_gates);
+    build_channel<N>(v[0], 0, angles, B, pc, amp & 1, trig, amp >> 1);
+    PG::fwd(v, prog, trig, umat, n_gates, amp >> 1);
     cl[0] = v[0];
   }
   float qb[N];
@@ -260,25 +273,39 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
     cl[1].re[k] = d * cl[0].re[k];
     cl[1].im[k] = d * cl[0].im[k];
   }
-  PG::bwd(cl, prog, trig, umat, n_gates, smem + wave * n_params, lane);
+  PG::bwd(cl, prog, trig, umat, n_gates, smem + wave * n_params, lane, amp >> 1);
   float T[N];
-  if (amp) {   // d L / d(initial amplitude k) = 2 Re Lambda_k  (the initial amplitudes are real)
+  if (amp & 1) {   // d L / d(initial amplitude k) = 2 Re Lambda_k  (the initial amplitudes are real)
 #pragma unroll
     for (int w = 0; w < N; ++w) T[w] = 2.f * cl[1].re[w];
   } else {
     float Q0[1 << N], Q1[1 << N], Q2[1 << N];
-    channel_series<N>(Q0, Q1, Q2, 0, qc_launder(angles), B, pc);
+    channel_series<N>(Q0, Q1, Q2, 0, qc_launder(angles), B, pc, trig, amp >> 1);
     qc_embed_ip<N>(T, cl[1], Q0);
   }
   if (live) {
 #pragma unroll
     for (int w = 0; w < N; ++w) d_angles[(int64_t)w * B + p] = T[w];
   }
+  if (amp >> 1) {   // folded RX layer: d L / d theta_w = sum over points of d L / d angle_w
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+      const float tot = qc_wave_sum_to_lane63(live ? T[w] : 0.f);
+      if (lane == 63) smem[wave * n_params + prog[w].slot] += tot;
+    }
+  }
   __syncthreads();
   // one partial row per wave = per 64-point tile (same tiling as the MLP kernels)
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   if (tile * 64 < B)
     for (int i = lane; i < n_params; i += 64) part[(row0 + tile) * part_stride + i] = smem[wave * n_params + i];
+}
+
+// Final-state store handed from k_jets_fwd to k_jets_bwd: tile-major, so the 6 x A2 x 64 floats one
+// block touches are one contiguous 6*A2*256-byte region (DRAM-page friendly), not A2 streams B apart.
+template <int A2>
+__device__ __forceinline__ int64_t qc_chi_index(int ch, int k2, int64_t p) {
+  return ((((p >> 6) * 6 + ch) * A2 + k2) << 6) | (p & 63);
 }
 
 // ================================================================== six derivative channels
@@ -297,13 +324,13 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
   const int64_t pc = p < B ? p : B - 1;
 
   SV<N> v[1];
-  build_channel<N>(v[0], ch, ajets, B, pc, amp);
-  PG::fwd(v, prog, trig, umat, n_gates);
+  build_channel<N>(v[0], ch, ajets, B, pc, amp & 1, trig, amp >> 1);
+  PG::fwd(v, prog, trig, umat, n_gates, amp >> 1);
   if (chi_store != nullptr && p < B) {   // final states for the adjoint kernel of the same step: [6][A2][B]
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
-      chi_store[((int64_t)ch * A2 + 2 * k) * B + p] = v[0].re[k];
-      chi_store[((int64_t)ch * A2 + 2 * k + 1) * B + p] = v[0].im[k];
+      chi_store[qc_chi_index<A2>(ch, 2 * k, p)] = v[0].re[k];
+      chi_store[qc_chi_index<A2>(ch, 2 * k + 1, p)] = v[0].im[k];
     }
   }
 
@@ -357,11 +384,13 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
   constexpr int N = PG::N;
   constexpr int A2 = 2 << N;
   extern __shared__ float smem[];
-  float* s_chi = smem;                       // [6][A2][64]; later reused as [6 waves][3][N][64]
-  float* s_acc = smem + 6 * A2 * 64;         // [6 waves][n_params]
+  constexpr int XCH = LOAD ? 6 * 3 * N * 64 : 6 * A2 * 64;   // exchange region (floats)
+  float* s_chi = smem;                       // !LOAD: [6][A2][64]; always reused as [6 waves][3][N][64] at the end
+  float* s_acc = smem + XCH;                 // [6 waves][n_params]
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 6 * n_params; i += 384) s_acc[i] = 0.f;
+  if constexpr (LOAD) __syncthreads();   // (the !LOAD path has its barrier after the state exchange)
 
   const int64_t p = (int64_t)blockIdx.x * 64 + lane;
   const bool live = p < B;
@@ -371,22 +400,33 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
   if constexpr (LOAD) {
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
-      cl[0].re[k] = chi_store[((int64_t)ch * A2 + 2 * k) * B + pc];
-      cl[0].im[k] = chi_store[((int64_t)ch * A2 + 2 * k + 1) * B + pc];
+      cl[0].re[k] = chi_store[qc_chi_index<A2>(ch, 2 * k, pc)];
+      cl[0].im[k] = chi_store[qc_chi_index<A2>(ch, 2 * k + 1, pc)];
     }
   } else {
     SV<N> v[1];
-    build_channel<N>(v[0], ch, ajets, B, pc, amp);
-    PG::fwd(v, prog, trig, umat, n_gates);
+    build_channel<N>(v[0], ch, ajets, B, pc, amp & 1, trig, amp >> 1);
+    PG::fwd(v, prog, trig, umat, n_gates, amp >> 1);
     cl[0] = v[0];
   }
-  float* mine = s_chi + ch * A2 * 64;
+  // The other channels' final states: through LDS when this launch computed them, straight from the
+  // forward kernel's store (L2-resident) when LOAD -- then no exchange buffer and no barrier is needed
+  // before the sweep, and the block's LDS shrinks to the small tail buffers.
+  if constexpr (!LOAD) {
+    float* mine = s_chi + ch * A2 * 64;
 #pragma unroll
-  for (int k = 0; k < (1 << N); ++k) {
-    mine[(2 * k) * 64 + lane] = cl[0].re[k];
-    mine[(2 * k + 1) * 64 + lane] = cl[0].im[k];
+    for (int k = 0; k < (1 << N); ++k) {
+      mine[(2 * k) * 64 + lane] = cl[0].re[k];
+      mine[(2 * k + 1) * 64 + lane] = cl[0].im[k];
+    }
+    __syncthreads();
   }
-  __syncthreads();
+  auto other_re = [&](int c, int k) {
+    return LOAD ? chi_store[qc_chi_index<A2>(c, 2 * k, pc)] : s_chi[(c * A2 + 2 * k) * 64 + lane];
+  };
+  auto other_im = [&](int c, int k) {
+    return LOAD ? chi_store[qc_chi_index<A2>(c, 2 * k + 1, pc)] : s_chi[(c * A2 + 2 * k + 1) * 64 + lane];
+  };
 
   // ---- cotangent of this channel's final state (bilinear <Z> forms)
   auto dvec = [&](int c, float (&d)[1 << N]) {
@@ -412,19 +452,18 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
 #pragma unroll 1
     for (int c = 1; c < QC_NCH; ++c) {   // one channel at a time: keeps the live set at one vector
       dvec(c, d);
-      const float* other = s_chi + c * A2 * 64;
 #pragma unroll
       for (int k = 0; k < (1 << N); ++k) {
-        cl[1].re[k] = fmaf(d[k], other[(2 * k) * 64 + lane], cl[1].re[k]);
-        cl[1].im[k] = fmaf(d[k], other[(2 * k + 1) * 64 + lane], cl[1].im[k]);
+        cl[1].re[k] = fmaf(d[k], other_re(c, k), cl[1].re[k]);
+        cl[1].im[k] = fmaf(d[k], other_im(c, k), cl[1].im[k]);
       }
     }
   } else {
     dvec(ch, d);
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
-      cl[1].re[k] = d[k] * s_chi[(2 * k) * 64 + lane];
-      cl[1].im[k] = d[k] * s_chi[(2 * k + 1) * 64 + lane];
+      cl[1].re[k] = d[k] * other_re(0, k);
+      cl[1].im[k] = d[k] * other_im(0, k);
     }
     if (ch == 2 || ch == 3) {
       dvec(ch + 2, d);
@@ -435,11 +474,11 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
       }
     }
   }
-  __syncthreads();  // everyone is done reading s_chi
+  if constexpr (!LOAD) __syncthreads();  // everyone is done reading s_chi
 
-  PG::bwd(cl, prog, trig, umat, n_gates, s_acc + ch * n_params, lane);
+  PG::bwd(cl, prog, trig, umat, n_gates, s_acc + ch * n_params, lane, amp >> 1);
 
-  if (amp) {
+  if (amp & 1) {
     // amplitude encoding: the channel's initial vector IS the input jet, so its cotangent is read off
     // the swept lambda directly: d L / d u_c[k] = 2 Re Lambda_c[k] (no coupling between channels here)
     if (live) {
@@ -451,7 +490,7 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
     // ---- cotangents of the angle jets: Im<Lambda| X_w |phi> against the embedding series, which is
     // rebuilt here (exact, and cheaper than carrying 3 * 2^n registers through the sweep)
     float P0[1 << N], P1[1 << N], P2[1 << N];
-    channel_series<N>(P0, P1, P2, ch, qc_launder(ajets), B, pc);
+    channel_series<N>(P0, P1, P2, ch, qc_launder(ajets), B, pc, trig, amp >> 1);
     float* buf = s_chi + ch * 3 * N * 64;  // [3][N][64] per wave
     float T[N];
     if (ch == 0) {
@@ -490,7 +529,12 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
       else
         r = at(ch, 2, w);
       if (live) abar[((int64_t)ch * N + w) * B + p] = r;
+      if ((amp >> 1) && ch == 0) {   // folded RX layer: d L / d theta_w = sum over points of d L / d angle_w
+        const float tot = qc_wave_sum_to_lane63(live ? r : 0.f);
+        if (lane == 63) s_acc[prog[w].slot] += tot;
+      }
     }
+    __syncthreads();
   }
   for (int i = threadIdx.x; i < n_params; i += 384) {
     float s = 0.f;
@@ -501,6 +545,13 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
 }
 
 }  // namespace
+
+// bit 0: amplitude encoding; bit 1: leading RX layer folded into the embedding (QC_NO_ABSORB=1 disables)
+static inline int qc_embed_flags(const qc_program* pg) {
+  static const bool off = [] { const char* e = getenv("QC_NO_ABSORB"); return e && e[0] == '1'; }();
+  const int absorb = (pg->lead_rx && !pg->amplitude && !off) ? 2 : 0;
+  return (pg->amplitude ? 1 : 0) | absorb;
+}
 
 // ------------------------------------------------------------------ launch helpers (per policy)
 struct QcRegLaunchers {
@@ -517,7 +568,7 @@ struct RegLaunch {
   static int value_fwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* angles,
                        float* expval, int64_t B, hipStream_t st) {
     hipLaunchKernelGGL(k_value_fwd<PG>, dim3(qc_ceil_div(B, 256)), dim3(256), 0, st, pg->d_gates, trig, umat,
-                       pg->n_gates, angles, expval, B, pg->amplitude);
+                       pg->n_gates, angles, expval, B, qc_embed_flags(pg));
     return QC_OK;
   }
   static int value_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* angles,
@@ -525,19 +576,20 @@ struct RegLaunch {
                        int64_t B, hipStream_t st) {
     const size_t sh = (size_t)4 * pg->n_params * sizeof(float);
     hipLaunchKernelGGL(k_value_bwd<PG>, dim3(qc_ceil_div(B, 256)), dim3(256), sh, st, pg->d_gates, trig, umat,
-                       pg->n_gates, pg->n_params, angles, cot, d_angles, part, part_stride, row0, B, pg->amplitude);
+                       pg->n_gates, pg->n_params, angles, cot, d_angles, part, part_stride, row0, B, qc_embed_flags(pg));
     return QC_OK;
   }
   static int jets_fwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
                       float* qjets, int64_t B, float* chi_store, hipStream_t st) {
     hipLaunchKernelGGL(k_jets_fwd<PG>, dim3(qc_ceil_div(B, 64)), dim3(384), 0, st, pg->d_gates, trig, umat,
-                       pg->n_gates, ajets, qjets, B, chi_store, pg->amplitude);
+                       pg->n_gates, ajets, qjets, B, chi_store, qc_embed_flags(pg));
     return QC_OK;
   }
   static int jets_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
                       const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
                       const float* chi_store, hipStream_t st) {
     const size_t sh = ((size_t)6 * (2u << PG::N) * 64 + (size_t)6 * pg->n_params) * sizeof(float);
+    const size_t sh_load = ((size_t)6 * 3 * PG::N * 64 + (size_t)6 * pg->n_params) * sizeof(float);
     if (sh > 160 * 1024) return QC_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
@@ -548,11 +600,11 @@ struct RegLaunch {
       attr_set = true;
     }
     if (chi_store != nullptr)
-      hipLaunchKernelGGL((k_jets_bwd<PG, true>), dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
-                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, pg->amplitude);
+      hipLaunchKernelGGL((k_jets_bwd<PG, true>), dim3(qc_ceil_div(B, 64)), dim3(384), sh_load, st, pg->d_gates, trig, umat,
+                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, qc_embed_flags(pg));
     else
       hipLaunchKernelGGL((k_jets_bwd<PG, false>), dim3(qc_ceil_div(B, 64)), dim3(384), sh, st, pg->d_gates, trig, umat,
-                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, pg->amplitude);
+                         pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, qc_embed_flags(pg));
     return QC_OK;
   }
   static constexpr QcRegLaunchers table() { return {&value_fwd, &value_bwd, &jets_fwd, &jets_bwd}; }

@@ -24,8 +24,10 @@ struct QcGate {
 
 // Per-gate trig table entry, rebuilt on device every time the parameters change.
 struct QcTrig {
-  float c;  // cos(theta/2)
-  float s;  // sin(theta/2)
+  float c;   // cos(theta/2)
+  float s;   // sin(theta/2)
+  float th;  // theta itself (used when a leading RX layer is folded into the embedding angles)
+  float pad;
 };
 
 struct qc_program {
@@ -38,6 +40,7 @@ struct qc_program {
   QcGate* h_gates;  // host copy
   void* hbm_plan;   // QcHbmPlan* for n >= 9 (staged execution), else null
   int amplitude;    // 1: amplitude encoding (initial state given directly), 0: RX angle embedding
+  int lead_rx;      // 1: gates 0..n-1 are RX on wires 0..n-1 (cascade, cross_mesh): RX(p_w) RX(a_w) = RX(a_w + p_w)
 };
 
 // Channel numbering of the derivative ("jet") channels carried through the network:

@@ -83,8 +83,11 @@ __global__ void __launch_bounds__(1024) k_adam(float* __restrict__ flat, int NP,
   if (prog != nullptr)
     for (int g = threadIdx.x; g < n_gates; g += blockDim.x) {
       const QcGate gt = prog[g];
-      QcTrig tr = {1.f, 0.f};
-      if (gt.op != QC_U4 && gt.slot >= 0) sincosf(0.5f * prm[theta_off + gt.slot], &tr.s, &tr.c);
+      QcTrig tr = {1.f, 0.f, 0.f, 0.f};
+      if (gt.op != QC_U4 && gt.slot >= 0) {
+        tr.th = prm[theta_off + gt.slot];
+        sincosf(0.5f * tr.th, &tr.s, &tr.c);
+      }
       trig[g] = tr;
     }
   if (threadIdx.x == 0) {
@@ -123,8 +126,11 @@ __global__ void k_prep_trig(const QcGate* __restrict__ prog, int n_gates, const 
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_gates) return;
   const QcGate gt = prog[g];
-  QcTrig tr = {1.f, 0.f};
-  if (gt.op != QC_U4 && gt.slot >= 0) sincosf(0.5f * theta[gt.slot], &tr.s, &tr.c);
+  QcTrig tr = {1.f, 0.f, 0.f, 0.f};
+  if (gt.op != QC_U4 && gt.slot >= 0) {
+    tr.th = theta[gt.slot];
+    sincosf(0.5f * tr.th, &tr.s, &tr.c);
+  }
   trig[g] = tr;
 }
 

@@ -66,7 +66,7 @@ class Circuit:
         self.amplitude = bool(amplitude)
         if self.amplitude:
             L.check(self.lib.qc_program_set_encoding(self.handle, 1), "qc_program_set_encoding")
-        self.trig = torch.zeros(2 * program.n_gates, dtype=torch.float32, device=device)
+        self.trig = torch.zeros(int(self.lib.qc_trig_bytes(self.handle)) // 4, dtype=torch.float32, device=device)
         self.umat = None
         if program.use_haar:
             if haar is None:
