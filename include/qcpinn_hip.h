@@ -154,7 +154,7 @@ typedef struct qc_step_desc {
   const float* X_val_dev; int64_t B_val;   /* IC points first, then BC points */
   float* ajets_res_dev; float* qjets_res_dev; float* qbar_res_dev; float* abar_res_dev; /* 6*n*B_res each */
   float* ajets_val_dev; float* qjets_val_dev; float* qbar_val_dev; float* abar_val_dev; /* n*B_val each */
-  float* part_dev; int64_t part_stride; int64_t part_rows_cap;
+  float* part_dev; int64_t part_stride; int64_t part_rows_cap;   /* scratch: rewritten and folded in place every step */
   float* flat_dev;                                                                       /* NP+3 */
   qc_pde pde;
   qc_opt_hyper hyper;

@@ -458,7 +458,18 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);
       if (e != hipSuccess) return hip_fail(e);
     }
-    if ((rc = qc_reduce_rows(d->part_dev, rows, d->part_stride, L.NP + 3, d->flat_dev, st))) return rc;
+    // the step owns its partial-row matrix, so the reduction folds it in place (two levels, fixed order);
+    // with the update phase in the same call the second level rides in the optimiser launch
+    const int RS = qc_opt_fold_rows(d->part_dev, rows, d->part_stride, L.NP + 3, st);
+    if (phases & QC_PHASE_UPDATE) {
+      if (!d->m_dev || !d->v_dev || !d->opt_state_dev) return QC_ERR_ARG;
+      QcOptHyper h;
+      memcpy(&h, &d->hyper, sizeof(h));
+      qc_opt_adam_fold(d->part_dev, d->part_stride, RS, d->flat_dev, L.NP, d->params_dev, d->m_dev, d->v_dev,
+                       (QcOptState*)d->opt_state_dev, h, d->hist_dev, d->hist_cap, d->prog, L.oTh, (QcTrig*)d->trig_dev, st);
+      return after_launch();
+    }
+    if ((rc = qc_reduce_rows(d->part_dev, RS, d->part_stride, L.NP + 3, d->flat_dev, st))) return rc;
   }
   if (phases & QC_PHASE_UPDATE) {
     if (!d->m_dev || !d->v_dev || !d->opt_state_dev) return QC_ERR_ARG;

@@ -94,59 +94,69 @@ __device__ __forceinline__ float qc_static_grad(const SV<NQ>& lam, const SV<NQ>&
 template <class SP>
 struct StatProg {
   static constexpr int N = SP::N;
+  // The (cos, sin) pairs of every parametric gate are fetched before the first gate (they are wave-uniform:
+  // scalar loads into SGPRs, batched by the compiler), so no gate starts by waiting on a scalar load.
+  struct Trig {
+    float c[SP::G], s[SP::G];
+  };
   template <int I>
-  __device__ static __forceinline__ void fwd_one(SV<N> (&v)[1], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, int absorb) {
+  __device__ static __forceinline__ void load_one(Trig& t, const QcTrig* __restrict__ trig) {
+    constexpr SGate g = SP::g[I];
+    t.c[I] = 1.f;
+    t.s[I] = 0.f;
+    if constexpr (g.op != QC_U4 && g.slot >= 0) {
+      t.c[I] = trig[I].c;
+      t.s[I] = trig[I].s;
+    }
+  }
+  template <int... Is>
+  __device__ static __forceinline__ void load_all(Trig& t, const QcTrig* __restrict__ trig,
+                                                  std::integer_sequence<int, Is...>) {
+    (load_one<Is>(t, trig), ...);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <int I>
+  __device__ static __forceinline__ void fwd_one(SV<N> (&v)[1], const Trig& t, const float* __restrict__ umat,
+                                                 int absorb) {
     constexpr SGate g = SP::g[I];
     if constexpr (I < N) {
       if (absorb) return;   // leading RX layer folded into the embedding angles
     }
-    float c = 1.f, s = 0.f;
-    if constexpr (g.op != QC_U4 && g.slot >= 0) {
-      const QcTrig tr = trig[I];
-      c = tr.c;
-      s = tr.s;
-    }
-    qc_static_gate<N, 1, false, g.op, g.ba, g.bb, g.slot>(v, c, s, umat);
+    qc_static_gate<N, 1, false, g.op, g.ba, g.bb, g.slot>(v, t.c[I], t.s[I], umat);
     __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from interleaving whole gates (register pressure)
   }
   template <int... Is>
-  __device__ static __forceinline__ void fwd_all(SV<N> (&v)[1], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, int absorb,
-                                                 std::integer_sequence<int, Is...>) {
-    (fwd_one<Is>(v, trig, umat, absorb), ...);
+  __device__ static __forceinline__ void fwd_all(SV<N> (&v)[1], const Trig& t, const float* __restrict__ umat,
+                                                 int absorb, std::integer_sequence<int, Is...>) {
+    (fwd_one<Is>(v, t, umat, absorb), ...);
   }
   __device__ static __forceinline__ void fwd(SV<N> (&v)[1], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
                                              const float* __restrict__ umat, int, int absorb) {
-    fwd_all(v, trig, umat, absorb, std::make_integer_sequence<int, SP::G>{});
+    Trig t;
+    load_all(t, trig, std::make_integer_sequence<int, SP::G>{});
+    fwd_all(v, t, umat, absorb, std::make_integer_sequence<int, SP::G>{});
   }
   // Reverse sweep.  Parameter slots are compile-time constants here, so the wave totals of the
   // gradient terms stay in registers (gacc[slot], valid in lane 63) and reach LDS once, after the
   // sweep, instead of one LDS read-modify-write round trip per gate.
   template <int J>
-  __device__ static __forceinline__ void bwd_one(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, float (&gacc)[SP::P > 0 ? SP::P : 1],
-                                                 int absorb) {
+  __device__ static __forceinline__ void bwd_one(SV<N> (&cl)[2], const Trig& t, const float* __restrict__ umat,
+                                                 float (&gacc)[SP::P > 0 ? SP::P : 1], int absorb) {
     constexpr int I = SP::G - 1 - J;
     constexpr SGate g = SP::g[I];
     if constexpr (I < N) {
       if (absorb) return;
     }
-    float c = 1.f, s = 0.f;
-    if constexpr (g.op != QC_U4 && g.slot >= 0) {
-      const QcTrig tr = trig[I];
-      c = tr.c;
-      s = tr.s;
+    if constexpr (g.op != QC_U4 && g.slot >= 0)
       gacc[g.slot] += qc_wave_sum_to_lane63(qc_static_grad<N, g.op, g.ba, g.bb>(cl[1], cl[0]));
-    }
-    qc_static_gate<N, 2, true, g.op, g.ba, g.bb, g.slot>(cl, c, s, umat);
+    qc_static_gate<N, 2, true, g.op, g.ba, g.bb, g.slot>(cl, t.c[I], t.s[I], umat);
     __builtin_amdgcn_sched_barrier(0);
   }
   template <int... Js>
-  __device__ static __forceinline__ void bwd_all(SV<N> (&cl)[2], const QcTrig* __restrict__ trig,
-                                                 const float* __restrict__ umat, float (&gacc)[SP::P > 0 ? SP::P : 1],
-                                                 int absorb, std::integer_sequence<int, Js...>) {
-    (bwd_one<Js>(cl, trig, umat, gacc, absorb), ...);
+  __device__ static __forceinline__ void bwd_all(SV<N> (&cl)[2], const Trig& t, const float* __restrict__ umat,
+                                                 float (&gacc)[SP::P > 0 ? SP::P : 1], int absorb,
+                                                 std::integer_sequence<int, Js...>) {
+    (bwd_one<Js>(cl, t, umat, gacc, absorb), ...);
   }
   __device__ static __forceinline__ void bwd(SV<N> (&cl)[2], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
                                              const float* __restrict__ umat, int, float* __restrict__ acc_wave,
@@ -154,7 +164,9 @@ struct StatProg {
     float gacc[SP::P > 0 ? SP::P : 1];
 #pragma unroll
     for (int k = 0; k < (SP::P > 0 ? SP::P : 1); ++k) gacc[k] = 0.f;
-    bwd_all(cl, trig, umat, gacc, absorb, std::make_integer_sequence<int, SP::G>{});
+    Trig t;
+    load_all(t, trig, std::make_integer_sequence<int, SP::G>{});
+    bwd_all(cl, t, umat, gacc, absorb, std::make_integer_sequence<int, SP::G>{});
 #pragma unroll
     for (int k = 0; k < SP::P; ++k)
       if (lane == 63) acc_wave[k] += gacc[k];   // lane 63 holds the wave totals

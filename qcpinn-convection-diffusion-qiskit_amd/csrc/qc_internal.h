@@ -80,6 +80,10 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
                 float* out_u, float* out_res, const float* in_ubar, const float* in_rbar, float* qbar,
                 float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t);
 int qc_opt_reduce_rows(const float* part, int64_t rows, int64_t stride, int ncols, float* out, hipStream_t);
+int qc_opt_fold_rows(float* part, int64_t rows, int64_t stride, int ncols, hipStream_t);
+int qc_opt_adam_fold(const float* part, int64_t stride, int RS, float* flat, int NP, float* prm, float* m, float* v,
+                     QcOptState* state, QcOptHyper hp, float* hist, int hist_cap, const qc_program* pg, int theta_off,
+                     QcTrig* trig, hipStream_t);
 int qc_opt_adam(float* flat, int NP, float* prm, float* m, float* v, QcOptState* state, QcOptHyper hp,
                 float* hist, int hist_cap, const qc_program* pg, int theta_off, QcTrig* trig, hipStream_t);
 int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t);

@@ -50,13 +50,29 @@ __device__ __forceinline__ float block_sum_1024(float v, float* s_red) {
 
 // One block.  flat = [grad[NP] | L_r, L_bc, L_ic].  Updates prm/m/v in place, advances the
 // scheduler, appends the loss to hist[step], and rebuilds the gate trig table from the NEW theta.
-__global__ void __launch_bounds__(1024) k_adam(float* __restrict__ flat, int NP, float* __restrict__ prm,
-                                               float* __restrict__ m, float* __restrict__ v,
-                                               QcOptState* __restrict__ st, QcOptHyper hp,
-                                               float* __restrict__ hist, int hist_cap,
-                                               const QcGate* __restrict__ prog, int n_gates, int theta_off,
-                                               QcTrig* __restrict__ trig) {
-  __shared__ float s_red[16];
+struct QcAdamArgs {
+  float* flat;
+  int NP;
+  float *prm, *m, *v;
+  QcOptState* st;
+  QcOptHyper hp;
+  float* hist;
+  int hist_cap;
+  const QcGate* prog;
+  int n_gates, theta_off;
+  QcTrig* trig;
+};
+
+__device__ __forceinline__ void adam_block(const QcAdamArgs& a, float* s_red) {
+  float* __restrict__ flat = a.flat;
+  const int NP = a.NP;
+  float *__restrict__ prm = a.prm, *__restrict__ m = a.m, *__restrict__ v = a.v;
+  QcOptState* __restrict__ st = a.st;
+  const QcOptHyper& hp = a.hp;
+  float* __restrict__ hist = a.hist;
+  const int hist_cap = a.hist_cap, n_gates = a.n_gates, theta_off = a.theta_off;
+  const QcGate* __restrict__ prog = a.prog;
+  QcTrig* __restrict__ trig = a.trig;
   float ss = 0.f;
   for (int i = threadIdx.x; i < NP; i += blockDim.x) ss += flat[i] * flat[i];
   const float norm = sqrtf(block_sum_1024(ss, s_red));
@@ -121,6 +137,163 @@ __global__ void __launch_bounds__(1024) k_adam(float* __restrict__ flat, int NP,
   }
 }
 
+__global__ void __launch_bounds__(1024) k_adam(QcAdamArgs a) {
+  __shared__ float s_red[16];
+  adam_block(a, s_red);
+}
+
+// First level of the step's own row reduction, in place: block (cb, rs) folds rows rs, rs + RS,
+// rs + 2 RS, ... of column block cb into row rs (only that block ever touches row rs of those columns).
+// The RS = gridDim.y surviving rows are added, in order, by k_adam_fold (same call) or k_reduce_rows.
+// 1 700 rows become ~7 dependent loads per wave on 384 blocks instead of ~27 on 12.
+constexpr int QC_RED_WAVES = 8;
+__global__ void __launch_bounds__(64 * QC_RED_WAVES) k_fold_rows(float* __restrict__ part, int64_t rows, int64_t stride,
+                                                                 int ncols) {
+  __shared__ float s[QC_RED_WAVES][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int RS = gridDim.y, rs = blockIdx.y;
+  float a0 = 0.f, a1 = 0.f;
+  if (col < ncols) {
+    int64_t r = rs + (int64_t)RS * wave;
+    const int64_t hop = (int64_t)RS * QC_RED_WAVES;
+    for (; r + hop < rows; r += 2 * hop) {
+      a0 += part[r * stride + col];
+      a1 += part[(r + hop) * stride + col];
+    }
+    if (r < rows) a0 += part[r * stride + col];
+  }
+  s[wave][lane] = a0 + a1;
+  __syncthreads();
+  if (wave == 0 && col < ncols) {
+    float t = s[0][lane];
+#pragma unroll
+    for (int w = 1; w < QC_RED_WAVES; ++w) t += s[w][lane];
+    part[(int64_t)rs * stride + col] = t;
+  }
+}
+
+// The optimiser update with everything it reads fetched in ONE round trip (state record, gradient or the
+// RS folded rows of it, moments, parameters), for NP + 3 <= 3 * 1024: a single-block kernel is a chain of
+// memory latencies, so the loads are issued together up front and the new theta reaches the trig table
+// through LDS instead of a store -> load of global memory.  Arithmetic identical to adam_block.
+// FOLD: flat[c] = part[0][c] + ... + part[RS-1][c] (second reduction level, fixed order) is formed here.
+constexpr int QC_ADAM_K = 3;
+template <bool FOLD>
+__global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* __restrict__ part, int64_t stride, int RS) {
+  __shared__ float s_red[16];
+  __shared__ float s_loss[3];
+  extern __shared__ float s_theta[];   // [n_theta]
+  const int NP = a.NP, tid = threadIdx.x;
+  const QcOptHyper& hp = a.hp;
+  const int step = a.st->step + 1;
+  const float lr = a.st->lr;
+  float best = a.st->best;
+  int bad = a.st->num_bad;
+  float g[QC_ADAM_K], mi[QC_ADAM_K], vi[QC_ADAM_K], pi[QC_ADAM_K];
+#pragma unroll
+  for (int k = 0; k < QC_ADAM_K; ++k) {
+    const int i = tid + k * 1024;
+    g[k] = mi[k] = vi[k] = pi[k] = 0.f;
+    if (i < NP) {
+      mi[k] = a.m[i];
+      vi[k] = a.v[i];
+      pi[k] = a.prm[i];
+    }
+    if (i < NP + 3) {
+      if constexpr (FOLD) {
+        float t = 0.f;
+        int q = 0;
+        for (; q + 8 <= RS; q += 8) {
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = part[(int64_t)(q + j) * stride + i];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t += x[j];
+        }
+        for (; q < RS; ++q) t += part[(int64_t)q * stride + i];
+        g[k] = t;
+      } else {
+        g[k] = a.flat[i];
+      }
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < QC_ADAM_K; ++k) {
+    const int i = tid + k * 1024;
+    if (i < NP) ss += g[k] * g[k];
+    else if (i < NP + 3) s_loss[i - NP] = g[k];
+  }
+  const float norm = sqrtf(block_sum_1024(ss, s_red));   // (its barriers also publish s_loss)
+  float coef = hp.max_norm / (norm + 1e-6f);
+  coef = coef > 1.f ? 1.f : coef;
+  const float b1 = (float)hp.beta1, b2 = (float)hp.beta2;
+  const double bc1 = 1.0 - pow(hp.beta1, (double)step);
+  const float bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)step));
+  const float step_size = (float)((double)lr / bc1);
+  const int n_theta = NP - a.theta_off;
+#pragma unroll
+  for (int k = 0; k < QC_ADAM_K; ++k) {
+    const int i = tid + k * 1024;
+    if (i < NP) {
+      const float gc = g[k] * coef;
+      const float mn = mi[k] + (1.f - b1) * (gc - mi[k]);
+      const float vn = b2 * vi[k] + (1.f - b2) * gc * gc;
+      const float denom = sqrtf(vn) / bc2s + hp.eps;
+      const float pn = pi[k] - step_size * (mn / denom);
+      a.flat[i] = gc;
+      a.m[i] = mn;
+      a.v[i] = vn;
+      a.prm[i] = pn;
+      if (a.prog != nullptr && i >= a.theta_off) s_theta[i - a.theta_off] = pn;
+    } else if (FOLD && i < NP + 3) {
+      a.flat[i] = g[k];
+    }
+  }
+  __syncthreads();
+  if (a.prog != nullptr)
+    for (int gi = tid; gi < a.n_gates; gi += 1024) {
+      const QcGate gt = a.prog[gi];
+      QcTrig tr = {1.f, 0.f, 0.f, 0.f};
+      if (gt.op != QC_U4 && gt.slot >= 0 && gt.slot < n_theta) {
+        tr.th = s_theta[gt.slot];
+        sincosf(0.5f * tr.th, &tr.s, &tr.c);
+      }
+      a.trig[gi] = tr;
+    }
+  if (tid == 0) {
+    const float lr_ = s_loss[0], lb = s_loss[1], li = s_loss[2];
+    const float loss = hp.w_res * lr_ + hp.w_bc * lb + hp.w_ic * li;
+    float new_lr = lr;
+    if (loss < best * (1.f - hp.sched_threshold)) {
+      best = loss;
+      bad = 0;
+    } else {
+      bad += 1;
+    }
+    if (bad > hp.sched_patience) {
+      const float cand = fmaxf(lr * hp.sched_factor, hp.sched_min_lr);
+      if (lr - cand > hp.sched_eps) new_lr = cand;
+      bad = 0;
+    }
+    QcOptState o;
+    o.lr = new_lr;
+    o.best = best;
+    o.num_bad = bad;
+    o.step = step;
+    o.last_loss = loss;
+    o.last_norm = norm;
+    o.loss_parts[0] = lr_;
+    o.loss_parts[1] = lb;
+    o.loss_parts[2] = li;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) o.pad[k] = 0;
+    *a.st = o;
+    if (a.hist != nullptr && step - 1 < a.hist_cap) a.hist[step - 1] = loss;
+  }
+}
+
 __global__ void k_prep_trig(const QcGate* __restrict__ prog, int n_gates, const float* __restrict__ theta,
                             QcTrig* __restrict__ trig) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -141,11 +314,45 @@ int qc_opt_reduce_rows(const float* part, int64_t rows, int64_t stride, int ncol
   return QC_OK;
 }
 
+static QcAdamArgs adam_args(float* flat, int NP, float* prm, float* m, float* v, QcOptState* state, QcOptHyper hp,
+                            float* hist, int hist_cap, const qc_program* pg, int theta_off, QcTrig* trig) {
+  QcAdamArgs a;
+  a.flat = flat; a.NP = NP; a.prm = prm; a.m = m; a.v = v; a.st = state; a.hp = hp; a.hist = hist; a.hist_cap = hist_cap;
+  a.prog = pg ? pg->d_gates : nullptr; a.n_gates = pg ? pg->n_gates : 0; a.theta_off = theta_off; a.trig = trig;
+  return a;
+}
+
+static bool adam_fast_ok(int NP) { return NP + 3 <= QC_ADAM_K * 1024; }
+
 int qc_opt_adam(float* flat, int NP, float* prm, float* m, float* v, QcOptState* state, QcOptHyper hp,
                 float* hist, int hist_cap, const qc_program* pg, int theta_off, QcTrig* trig, hipStream_t st) {
-  hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, st, flat, NP, prm, m, v, state, hp, hist, hist_cap,
-                     pg ? pg->d_gates : nullptr, pg ? pg->n_gates : 0, theta_off, trig);
+  const QcAdamArgs a = adam_args(flat, NP, prm, m, v, state, hp, hist, hist_cap, pg, theta_off, trig);
+  if (adam_fast_ok(NP))
+    hipLaunchKernelGGL((k_adam_fast<false>), dim3(1), dim3(1024), sizeof(float) * (pg ? NP - theta_off : 0), st, a,
+                       (const float*)nullptr, (int64_t)0, 0);
+  else
+    hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, st, a);
   return QC_OK;
+}
+
+// In-place first level over the step's own partial-row matrix; returns the number of surviving rows.
+int qc_opt_fold_rows(float* part, int64_t rows, int64_t stride, int ncols, hipStream_t st) {
+  const int RS = (int)(rows < 32 ? rows : 32);
+  hipLaunchKernelGGL(k_fold_rows, dim3(qc_ceil_div(ncols, 64), RS), dim3(64 * QC_RED_WAVES), 0, st, part, rows, stride, ncols);
+  return RS;
+}
+
+// Second level + optimiser update (flat = [grad | 3 loss parts] is written as well).
+int qc_opt_adam_fold(const float* part, int64_t stride, int RS, float* flat, int NP, float* prm, float* m, float* v,
+                     QcOptState* state, QcOptHyper hp, float* hist, int hist_cap, const qc_program* pg, int theta_off,
+                     QcTrig* trig, hipStream_t st) {
+  if (adam_fast_ok(NP)) {
+    hipLaunchKernelGGL((k_adam_fast<true>), dim3(1), dim3(1024), sizeof(float) * (pg ? NP - theta_off : 0), st,
+                       adam_args(flat, NP, prm, m, v, state, hp, hist, hist_cap, pg, theta_off, trig), part, stride, RS);
+    return QC_OK;
+  }
+  qc_opt_reduce_rows(part, RS, stride, NP + 3, flat, st);
+  return qc_opt_adam(flat, NP, prm, m, v, state, hp, hist, hist_cap, pg, theta_off, trig, st);
 }
 
 int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t st) {
