@@ -499,31 +499,39 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
     }
     __syncthreads();
   } else {
-    // ---- cotangents of the angle jets: Im<Lambda| X_w |phi> against the embedding series, which is
-    // rebuilt here (exact, and cheaper than carrying 3 * 2^n registers through the sweep)
-    float P0[1 << N], P1[1 << N], P2[1 << N];
-    channel_series<N>(P0, P1, P2, ch, qc_launder(ajets), B, pc, trig, amp >> 1);
+    // ---- cotangents of the angle jets: Im<Lambda| X_w |phi_c>, evaluated in the frame pulled back through
+    // the embedding (qc_gates.h): un-apply the n embedding rotations on Lambda, then sparse reads
+    const float* aj = qc_launder(ajets);
+    float ca[N], sa[N], da[N], dda[N];
+    load_sincos<N>(ca, sa, aj, B, pc, trig, amp >> 1);
+    qc_unembed<N>(cl[1], ca, sa);
+    const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);  // channel holding the first derivative
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+      da[w] = ch >= 1 ? aj[((int64_t)dirch * N + w) * B + pc] : 0.f;
+      dda[w] = ch >= 4 ? aj[((int64_t)ch * N + w) * B + pc] : 0.f;
+    }
     float* buf = s_chi + ch * 3 * N * 64;  // [3][N][64] per wave
     float T[N];
     if (ch == 0) {
-      qc_embed_ip<N>(T, cl[1], P0);
+      qc_pull_ip0<N>(T, cl[1]);
   #pragma unroll
       for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
     } else if (ch <= 3) {
-      qc_embed_ip<N>(T, cl[1], P1);
+      qc_pull_ip1<N>(T, cl[1], da);
   #pragma unroll
       for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
-      qc_embed_ip<N>(T, cl[1], P0);
+      qc_pull_ip0<N>(T, cl[1]);
   #pragma unroll
       for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = T[w];
     } else {
-      qc_embed_ip<N>(T, cl[1], P2);
+      qc_pull_ip2<N>(T, cl[1], da, dda);
   #pragma unroll
       for (int w = 0; w < N; ++w) buf[(0 * N + w) * 64 + lane] = T[w];
-      qc_embed_ip<N>(T, cl[1], P1);
+      qc_pull_ip1<N>(T, cl[1], da);
   #pragma unroll
       for (int w = 0; w < N; ++w) buf[(1 * N + w) * 64 + lane] = 2.f * T[w];
-      qc_embed_ip<N>(T, cl[1], P0);
+      qc_pull_ip0<N>(T, cl[1]);
   #pragma unroll
       for (int w = 0; w < N; ++w) buf[(2 * N + w) * 64 + lane] = T[w];
     }

@@ -391,6 +391,61 @@ __device__ __forceinline__ void qc_embed_ip(float (&T)[N], const SV<N>& lam, con
   }
 }
 
+// ---- embedding cotangents in the pulled-back frame
+// The embedding U = prod_w RX(a_w) commutes with every X_w, so Im<Lam| X_w U |kappa> = Im<mu| X_w |kappa>
+// with mu = U^dagger Lam, and the channel states are U applied to SPARSE vectors (G_v = -i X_v / 2):
+//   kappa_0  = |0>,   kappa_s = sum_v da_v G_v |0>,   kappa_ss = [(sum_v da_v G_v)^2 + sum_v dda_v G_v] |0>,
+// supported on basis states of weight <= 1 / <= 2.  Un-applying the n rotations on Lam (qc_unembed) and
+// reading a few amplitudes of mu replaces rebuilding the product series and dense inner products.
+template <int N, int W = 0>
+__device__ __forceinline__ void qc_unembed(SV<N>& v, const float (&ca)[N], const float (&sa)[N]) {
+  if constexpr (W < N) {
+    g_rx<N, N - 1 - W>(v, ca[W], -sa[W]);
+    qc_unembed<N, W + 1>(v, ca, sa);
+  }
+}
+// T[w] = Im <mu| X_w |kappa_0>
+template <int N>
+__device__ __forceinline__ void qc_pull_ip0(float (&T)[N], const SV<N>& mu) {
+#pragma unroll
+  for (int w = 0; w < N; ++w) T[w] = -mu.im[1 << (N - 1 - w)];
+}
+// T[w] = Im <mu| X_w |kappa_s>
+template <int N>
+__device__ __forceinline__ void qc_pull_ip1(float (&T)[N], const SV<N>& mu, const float (&da)[N]) {
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    const int bw = 1 << (N - 1 - w);
+    float acc = da[w] * mu.re[0];
+#pragma unroll
+    for (int v = 0; v < N; ++v)
+      if (v != w) acc = fmaf(da[v], mu.re[bw | (1 << (N - 1 - v))], acc);
+    T[w] = -0.5f * acc;
+  }
+}
+// T[w] = Im <mu| X_w |kappa_ss>
+template <int N>
+__device__ __forceinline__ void qc_pull_ip2(float (&T)[N], const SV<N>& mu, const float (&da)[N],
+                                            const float (&dda)[N]) {
+  float S = 0.f;
+#pragma unroll
+  for (int v = 0; v < N; ++v) S = fmaf(da[v], da[v], S);
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    const int bw = 1 << (N - 1 - w);
+    float a = S * mu.im[bw];
+    float b = dda[w] * mu.re[0];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      if (u != w) b = fmaf(dda[u], mu.re[bw | (1 << (N - 1 - u))], b);
+#pragma unroll
+      for (int v = u + 1; v < N; ++v)
+        a = fmaf(2.f * da[u] * da[v], mu.im[(1 << (N - 1 - u)) ^ (1 << (N - 1 - v)) ^ bw], a);
+    }
+    T[w] = 0.25f * a - 0.5f * b;
+  }
+}
+
 // <Z_w> style signed sums: out[w] = sum_k t[k] * (1 - 2 bit_{N-1-w}(k))
 template <int N>
 __device__ __forceinline__ void qc_signed_sums(float (&out)[N], const float (&t)[1 << N]) {
