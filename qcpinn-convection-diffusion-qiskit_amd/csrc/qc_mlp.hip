@@ -125,13 +125,13 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
   }
   __syncthreads();
 
-  const int grp = threadIdx.x / HB, m = threadIdx.x % HB;
-  const int per = 64 / PS;
+  const int grp = threadIdx.x / HB, m = threadIdx.x % HB;   // threads past HB * PS (block rounded up to waves) idle
+  const int per = (64 + PS - 1) / PS;
   const int p0 = grp * per, p1 = (p0 + per) < cnt ? (p0 + per) : cnt;
   float gW1[3] = {0.f, 0.f, 0.f}, gb1 = 0.f, gW2[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) gW2[i] = 0.f;
-  if (m < L.H) {
+  if (grp < PS && m < L.H) {
     const float w0 = prm[L.oW1 + 3 * m], w1 = prm[L.oW1 + 3 * m + 1], w2 = prm[L.oW1 + 3 * m + 2];
     const float bb = prm[L.ob1 + m];
     float w2c[N];
@@ -178,13 +178,15 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
       }
     }
   }
-  float* mine = s_acc + (size_t)grp * (4 + N) * HB;
-  mine[0 * HB + m] = gW1[0];
-  mine[1 * HB + m] = gW1[1];
-  mine[2 * HB + m] = gW1[2];
-  mine[3 * HB + m] = gb1;
+  if (grp < PS) {
+    float* mine = s_acc + (size_t)grp * (4 + N) * HB;
+    mine[0 * HB + m] = gW1[0];
+    mine[1 * HB + m] = gW1[1];
+    mine[2 * HB + m] = gW1[2];
+    mine[3 * HB + m] = gb1;
 #pragma unroll
-  for (int i = 0; i < N; ++i) mine[(4 + i) * HB + m] = gW2[i];
+    for (int i = 0; i < N; ++i) mine[(4 + i) * HB + m] = gW2[i];
+  }
   __syncthreads();
   float* row = part + (row0 + blockIdx.x) * part_stride;
   if (grp == 0 && m < L.H) {
@@ -420,13 +422,13 @@ __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, 
     sU[k][pp] = (pp < cnt && src != nullptr) ? src[base + pp] : 0.f;
   }
   __syncthreads();
-  const int grp = threadIdx.x / HB, m = threadIdx.x % HB;
-  const int per = 64 / PS;
+  const int grp = threadIdx.x / HB, m = threadIdx.x % HB;   // threads past HB * PS (block rounded up to waves) idle
+  const int per = (64 + PS - 1) / PS;
   const int p0 = grp * per, p1 = (p0 + per) < cnt ? (p0 + per) : cnt;
   float gW3[N], gb3 = 0.f, gW4 = 0.f;
 #pragma unroll
   for (int i = 0; i < N; ++i) gW3[i] = 0.f;
-  if (m < L.H) {
+  if (grp < PS && m < L.H) {
     float w3[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) w3[i] = prm[L.oW3 + m * N + i];
@@ -456,11 +458,13 @@ __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, 
       }
     }
   }
-  float* mine = s_acc + (size_t)grp * (N + 2) * HB;
+  if (grp < PS) {
+    float* mine = s_acc + (size_t)grp * (N + 2) * HB;
 #pragma unroll
-  for (int i = 0; i < N; ++i) mine[i * HB + m] = gW3[i];
-  mine[N * HB + m] = gb3;
-  mine[(N + 1) * HB + m] = gW4;
+    for (int i = 0; i < N; ++i) mine[i * HB + m] = gW3[i];
+    mine[N * HB + m] = gb3;
+    mine[(N + 1) * HB + m] = gW4;
+  }
   __syncthreads();
   float* row = part + (row0 + blockIdx.x) * part_stride;
   if (grp == 0 && m < L.H) {
@@ -497,10 +501,21 @@ __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, 
     default: return QC_ERR_UNSUPPORTED;                                                            \
   }
 
-static inline void hidden_geometry(int H, int* HB, int* PS) {
-  *HB = 64 * qc_ceil_div(H, 64);
-  int ps = 1024 / *HB;
-  *PS = ps >= 4 ? 4 : (ps >= 2 ? 2 : 1);
+// lane = hidden unit kernels: HB lanes per group (one per hidden unit), PS groups share the tile's 64
+// points.  Narrow hidden layers pack groups back to back (HB = H: 10 groups of 50 fill 500 of 512 lanes
+// instead of 4 x 64 with 14 idle lanes each); the block is rounded up to whole waves.
+static inline void hidden_geometry(int H, int* HB, int* PS, int* threads) {
+  static const int target = [] { const char* e = getenv("QC_MLP_THREADS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 512; }();
+  if (H <= target) {
+    *HB = H;
+    int ps = target / H;
+    *PS = ps > 64 ? 64 : ps;
+  } else {
+    *HB = 64 * qc_ceil_div(H, 64);
+    int ps = 1024 / *HB;
+    *PS = ps >= 4 ? 4 : (ps >= 2 ? 2 : 1);
+  }
+  *threads = 64 * qc_ceil_div(*HB * *PS, 64);
 }
 
 int qc_mlp_pre_fwd(const float* X, const float* prm, QcLayout L, float* ajets, int64_t B, int nch,
@@ -518,9 +533,8 @@ int qc_mlp_pre_bwd(const float* X, const float* prm, QcLayout L, const float* ab
                    int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t st) {
   const int grid = qc_ceil_div(B, 64);
   if (L.H > 1024 || L.n > 64) return QC_ERR_UNSUPPORTED;
-  int HB, PS;
-  hidden_geometry(L.H, &HB, &PS);
-  const int threads = HB * PS;
+  int HB, PS, threads;
+  hidden_geometry(L.H, &HB, &PS, &threads);
   const size_t sh = (size_t)PS * (4 + L.n) * HB * sizeof(float);
 #define CALL(NN)                                                                                               \
   if (nch == 6) hipLaunchKernelGGL((k_pre_bwd<NN, 6>), dim3(grid), dim3(threads), sh, st, X, prm, L, abar, part, \
@@ -537,8 +551,8 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
                 float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t st) {
   const int tiles = qc_ceil_div(B, 64);
   if (L.H > 1024) return QC_ERR_UNSUPPORTED;
-  int HB, PS;
-  hidden_geometry(L.H, &HB, &PS);
+  int HB, PS, threads;
+  hidden_geometry(L.H, &HB, &PS, &threads);
   const size_t sh = (size_t)PS * (L.n + 2) * HB * sizeof(float);
   // cotangent sources of the weight-gradient kernel: given (mode 1) or produced by the point kernel (mode 2)
   const float* ub_src = mode == 1 ? in_ubar : out_u;
@@ -547,7 +561,7 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
   hipLaunchKernelGGL((k_post<NN, CC, MM>), dim3(tiles), dim3(256), 0, st, X, prm, L, pde, qjets, out_u,  \
                      out_res, in_ubar, in_rbar, qbar, part, part_stride, row0, B)
 #define LAUNCH_WG(NN, CC)                                                                               \
-  hipLaunchKernelGGL((k_post_wg<NN, CC>), dim3(tiles), dim3(HB * PS), sh, st, prm, L, pde, qjets,        \
+  hipLaunchKernelGGL((k_post_wg<NN, CC>), dim3(tiles), dim3(threads), sh, st, prm, L, pde, qjets,        \
                      ub_src, (CC == 6 ? rb_src : nullptr), part, part_stride, row0, B, HB, PS)
 #define CALL(NN)                                                         \
   if (nch == 6) {                                                        \
