@@ -221,6 +221,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         one_step()
+    t_enqueue = time.perf_counter() - t0           # host time to enqueue the K steps (no sync inside a step)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -252,7 +253,7 @@ def main():
                                    f"{a.batch_per_gpu} residual + 2x{a.batch_per_gpu // 3} BC/IC points per GPU",
                        "global_batch": global_batch, "parallelism": f"dp{world}",
                        "total_points_per_s": a.steps * (global_batch + 2 * (global_batch // 3)) / dt,
-                       "final_loss": rec["loss"]},
+                       "final_loss": rec["loss"], "host_enqueue_ms_per_step": t_enqueue / a.steps * 1e3},
             "roofline": {"bound": "mfma", "pipe": "fp32 VALU (no MFMA used; fp32 vector peak == fp32 MFMA peak)",
                          "kernel": dom, "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F32_TFLOPS, "traffic": measured_traffic(dom),
