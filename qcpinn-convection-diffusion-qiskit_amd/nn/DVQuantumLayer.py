@@ -12,6 +12,11 @@ its backward is the HIP adjoint sweep.  There is no CPU path: a CPU input raises
 features, zero-padded and L2-normalised, are the initial statevector; anything else is the RX angle
 embedding (:182), as in the reference.
 
+Derivatives: the reverse pass w.r.t. angles and parameters is the HIP adjoint sweep; with
+``create_graph=True`` (generic ``diffusion_operator`` on an arbitrary model) the reverse pass is
+re-expressed through the exact trigonometric-interpolation form of the layer, so second and higher
+input derivatives work as with the reference's backprop simulator (angle encoding, n <= 7).
+
 Out of scope, by design: IBM Runtime devices / shot-based execution
 (``use_ibm_hardware=True``) are refused with an explicit error.
 """
@@ -25,8 +30,78 @@ from ..hip import engine as _engine
 from ..hip.lib import QcError
 
 
+# Largest register count for which higher-order input derivatives (create_graph=True) are provided:
+# the trigonometric-interpolation form below has 3^n coefficients per output wire.
+TRIG_INTERP_MAX_QUBITS = 7
+
+
+def _trig_nodes(n: int, device) -> torch.Tensor:
+    """(3^n, n) grid of embedding angles {0, 2pi/3, 4pi/3}^n, wire 0 the slowest index."""
+    a = torch.tensor([0.0, 2.0 * torch.pi / 3.0, 4.0 * torch.pi / 3.0], dtype=torch.float32, device=device)
+    return torch.cartesian_prod(*([a] * n)).reshape(-1, n) if n > 1 else a.reshape(-1, 1)
+
+
+def _trig_finv(device) -> torch.Tensor:
+    a = torch.tensor([0.0, 2.0 * torch.pi / 3.0, 4.0 * torch.pi / 3.0], dtype=torch.float64)
+    F = torch.stack([torch.ones_like(a), torch.cos(a), torch.sin(a)], 1)        # F[j, k] = f_k(alpha_j)
+    return torch.linalg.inv(F).to(device)                                        # (3, 3) float64
+
+
+def _mode_products(T: torch.Tensor, M: torch.Tensor, n: int) -> torch.Tensor:
+    """T (..., 3, 3, ..., 3) with n trailing axes of size 3: contracts every one of them with M[k, j]."""
+    for ax in range(T.dim() - n, T.dim()):
+        T = torch.movedim(torch.tensordot(T, M, dims=([ax], [1])), -1, ax)
+    return T
+
+
+class _TrigCoeffFn(torch.autograd.Function):
+    """theta (L, P) -> C (n, 3^n): coefficients of <Z_v>(a) = sum_k C[v, k] prod_w f_{k_w}(a_w) with
+    f = (1, cos, sin).  Every embedding angle enters through ONE RX gate, so each <Z_v> is a degree-1
+    trigonometric polynomial in each a_w: evaluating the circuit (HIP statevector kernels) on the 3^n grid
+    {0, 2pi/3, 4pi/3}^n and inverting the 3x3 node matrix per wire gives the coefficients exactly.  The
+    reverse pass is the HIP adjoint sweep on the same grid (first order in theta)."""
+
+    @staticmethod
+    def forward(ctx, params, layer, device):
+        circ = layer._circuit_for(device)
+        n = layer.num_qubits
+        theta = params.detach().to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+        nodes = _trig_nodes(n, device).t().contiguous()                      # (n, 3^n)
+        circ.prepare(theta)
+        E = circ.forward_expval(nodes)                                           # (n, 3^n)
+        finv = _trig_finv(device)
+        C = _mode_products(E.to(torch.float64).reshape((n,) + (3,) * n), finv, n)
+        ctx.circ, ctx.n = circ, n
+        ctx.save_for_backward(nodes, theta, finv)
+        ctx.pshape, ctx.pdev = params.shape, params.device
+        return C.reshape(n, -1).to(torch.float32)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gC):
+        nodes, theta, finv = ctx.saved_tensors
+        n = ctx.n
+        gE = _mode_products(gC.to(torch.float64).reshape((n,) + (3,) * n), finv.t().contiguous(), n)
+        ctx.circ.prepare(theta)
+        _, d_theta = ctx.circ.backward_expval(nodes, gE.reshape(n, -1).to(torch.float32).contiguous())
+        return d_theta.reshape(ctx.pshape).to(ctx.pdev), None, None
+
+
+def _trig_features(x: torch.Tensor) -> torch.Tensor:
+    """(B, n) angles -> (B, 3^n) products of (1, cos a_w, sin a_w), wire 0 the slowest index."""
+    phi = torch.ones(x.shape[0], 1, dtype=x.dtype, device=x.device)
+    for w in range(x.shape[1]):
+        f = torch.stack([torch.ones_like(x[:, w]), torch.cos(x[:, w]), torch.sin(x[:, w])], 1)
+        phi = (phi[:, :, None] * f[:, None, :]).reshape(x.shape[0], -1)
+    return phi
+
+
 class _ExpvalFn(torch.autograd.Function):
-    """angles (B, n), theta (L, P) -> <Z> (n, B); first-order differentiable in both."""
+    """angles (B, n), theta (L, P) -> <Z> (n, B).  Forward and the ordinary reverse pass are the HIP
+    statevector kernels.  Under ``create_graph=True`` (the reference's nn/pde.py:59-70 usage on an
+    arbitrary model) the reverse pass is rebuilt from differentiable torch ops on the exact
+    trigonometric-interpolation form of the same function (coefficients from the HIP kernels), so input
+    derivatives of any order exist; theta stays first order."""
 
     @staticmethod
     def forward(ctx, x, params, layer):
@@ -35,20 +110,31 @@ class _ExpvalFn(torch.autograd.Function):
         theta = params.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         circ.prepare(theta)
         out = circ.forward_expval(angles)
-        ctx.circ = circ
-        ctx.save_for_backward(angles, theta)
-        ctx.pshape = params.shape
-        ctx.pdev = params.device
+        ctx.circ, ctx.layer = circ, layer
+        ctx.save_for_backward(x, params)
         return out
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, grad_out):
-        angles, theta = ctx.saved_tensors
-        circ = ctx.circ
+        x, params = ctx.saved_tensors
+        circ, layer = ctx.circ, ctx.layer
+        if torch.is_grad_enabled():          # create_graph=True: the result must itself be differentiable
+            if layer.encoding == "amplitude" or layer.num_qubits > TRIG_INTERP_MAX_QUBITS:
+                raise NotImplementedError(
+                    "higher-order derivatives through DVQuantumLayer are provided for angle encoding and "
+                    f"num_qubits <= {TRIG_INTERP_MAX_QUBITS}; DVPDESolver.residual / diffusion_operator on a "
+                    "DVPDESolver use the fused derivative channels for any supported size")
+            q = layer.trig_interpolant(x, params)
+            wanted = [t for t in (x, params) if t.requires_grad]
+            got = list(torch.autograd.grad(q, wanted, grad_out.to(q.dtype), create_graph=True, allow_unused=True))
+            gx = got.pop(0) if x.requires_grad else None
+            gp = got.pop(0) if params.requires_grad else None
+            return gx, gp, None
+        angles = x.detach().to(torch.float32).t().contiguous()
+        theta = params.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
         circ.prepare(theta)          # another forward may have re-used the trig table since
         d_angles, d_theta = circ.backward_expval(angles, grad_out.to(torch.float32).contiguous())
-        return d_angles.t(), d_theta.reshape(ctx.pshape).to(ctx.pdev), None
+        return d_angles.t().to(x.dtype), d_theta.reshape(params.shape).to(params.device), None
 
 
 class DVQuantumLayer(nn.Module):
@@ -101,6 +187,14 @@ class DVQuantumLayer(nn.Module):
         if x.dim() != 2 or x.shape[1] != self.num_qubits:
             raise ValueError(f"expected angles of shape (B, {self.num_qubits}), got {tuple(x.shape)}")
         return _ExpvalFn.apply(x, self.params, self)
+
+    def trig_interpolant(self, x: torch.Tensor, params: torch.Tensor = None) -> torch.Tensor:
+        """The same (n, B) expectation values as ``forward`` written as a trigonometric polynomial of the
+        embedding angles (coefficients from the HIP kernels, see ``_TrigCoeffFn``): built from torch ops, so
+        derivatives with respect to ``x`` exist to any order.  Used for the create_graph=True reverse pass."""
+        params = self.params if params is None else params
+        C = _TrigCoeffFn.apply(params, self, x.device)                       # (n, 3^n)
+        return C @ _trig_features(x.to(torch.float32)).t()
 
     def circuit(self, x):
         """The reference exposes the QNode as ``.circuit``; calling it returns the per-wire list."""
