@@ -102,8 +102,16 @@ typedef struct qc_pde {
   float inv_n_res;        /* 1/N for the logged MSE */
   float w_val_a, w_val_b; /* same for the value segments: a = IC (weight 2), b = BC (weight 4) */
   float inv_n_a, inv_n_b;
+  int problem;            /* analytic targets of mode 2: QC_PROBLEM_CONVECTION_DIFFUSION (0) or QC_PROBLEM_PURE_DIFFUSION (1) */
   int64_t n_seg_a;        /* leading value points that are IC points */
 } qc_pde;
+
+/* 0: trainer/diffusion_train.py + data/diffusion_dataset.py:20-38 (Gaussian u on IC and BC1 points, forcing
+ *    term r incl. its -400 constant on residual points);
+ * 1: the reference's second workload train_hybrid_qpinn.py:116-131,159-203: u = sin(pi x) sin(pi y) exp(-2 pi^2 D t)
+ *    on IC points, 0 on the four boundary faces, residual target 0 (pure diffusion: set vx = vy = 0). */
+#define QC_PROBLEM_CONVECTION_DIFFUSION 0
+#define QC_PROBLEM_PURE_DIFFUSION 1
 
 /* mode 0: qjets -> u [B], residual [B] (nn/pde.py:71);
  * mode 1: cotangents (ubar, rbar) [B] -> qbar jets + weight-gradient partial rows;
@@ -138,6 +146,12 @@ int qc_adam_step(float* flat_dev, int NP, float* params_dev, float* m_dev, float
  * disjoint shards of the batch a single GPU would draw.  X_val holds the IC points first, then BC. */
 int qc_sample_collocation(float* X_res_dev, int64_t n_res, int64_t off_res, float* X_val_dev, int64_t n_ic,
                           int64_t off_ic, int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, void* stream);
+/* Same, with the boundary batch spread over the four faces x=0, x=1, y=0, y=1 in that order
+ * (train_hybrid_qpinn.py:166-176,689-697): GLOBAL boundary point g lies on face g / bc_face_points.
+ * bc_face_points = 0 is the single x=0 face of qc_sample_collocation. */
+int qc_sample_collocation_faces(float* X_res_dev, int64_t n_res, int64_t off_res, float* X_val_dev, int64_t n_ic,
+                                int64_t off_ic, int64_t n_bc, int64_t off_bc, int64_t bc_face_points, uint64_t seed,
+                                uint64_t step, void* stream);
 
 /* ---- one whole training step (trainer/diffusion_train.py:30-49,81-90) on resident batches:
  * residual batch through the 6-channel pipeline, IC+BC batch through the value pipeline,
@@ -162,6 +176,7 @@ typedef struct qc_step_desc {
   int64_t n_ic;                 /* leading IC points of the value batch (== pde.n_seg_a) */
   int64_t sample_off_res, sample_off_ic, sample_off_bc;
   uint64_t sample_seed, sample_step;
+  int64_t sample_bc_face_points; /* 0: BC batch on the x=0 face; > 0: four faces, see qc_sample_collocation_faces */
   void* circ_ws_dev; size_t circ_ws_bytes;   /* qc_step_workspace_bytes(prog, B_res, B_val); NULL/0 allowed for angle encoding at n <= 8 */
 } qc_step_desc;
 

@@ -182,3 +182,85 @@ def train(model, batch_size=128):
     for _ in range(model.epochs + 1):
         train_step(model, batch_size)
     return time.time() - t0
+
+
+# ================================================================== second workload: train_hybrid_qpinn.py
+# PARITY UNPINNED: the reference file imports PennyLane at module level (train_hybrid_qpinn.py:33), so none of
+# it can be imported here and it holds no fixtures; the functions below restate it line by line.
+TWIN_BOX_IC = ((0.0, 0.0, 0.0), (0.0, 1.0, 1.0))                       # train_hybrid_qpinn.py:162-164
+TWIN_BOX_BC = (((0.0, 0.0, 0.0), (1.0, 0.0, 1.0)), ((0.0, 1.0, 0.0), (1.0, 1.0, 1.0)),       # :166-176 x=0, x=1,
+               ((0.0, 0.0, 0.0), (1.0, 1.0, 0.0)), ((0.0, 0.0, 1.0), (1.0, 1.0, 1.0)))       #          y=0, y=1
+
+
+def twin_analytic_u(X, D=0.01):                                         # :127-131
+    t, x, y = X[:, 0:1], X[:, 1:2], X[:, 2:3]
+    pi = torch.pi
+    return torch.sin(pi * x) * torch.sin(pi * y) * torch.exp(-2 * pi ** 2 * D * t)
+
+
+class OracleHybridQPINN(OracleSolver):
+    """HybridQPINN of train_hybrid_qpinn.py:539-622 around the oracle layer: 1-D ``params = randn(P) * 0.1``
+    (:416), xavier-normal weights / zero biases on ALL four Linear layers (:594-600), plateau patience 500
+    (:583-585).  Construction order (hence RNG consumption) as there: pre, quantum params, post, re-init."""
+
+    def __init__(self, num_qubits=4, ansatz="cascade", hidden=50, lr=0.005, seed=42, encoding="angle"):
+        rng = torch.get_rng_state()
+        args = {"num_qubits": num_qubits, "num_quantum_layers": 1, "q_ansatz": ansatz, "epochs": 0, "lr": lr,
+                "classic_network": [3, hidden, 1], "seed": seed, "encoding": encoding}
+        super().__init__(args)
+        torch.set_rng_state(rng)
+        twin_initialise(self, hidden)
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=lr)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode="min", factor=0.9,
+                                                                    patience=500)
+
+
+def twin_initialise(model, hidden):
+    """Draws the initial weights in the order train_hybrid_qpinn.py:548-600 consumes the RNG and writes them
+    into ``model`` (submodules ``preprocessor``, ``quantum_layer``, ``postprocessor``)."""
+    n = model.num_qubits
+    pre = [nn.Linear(3, hidden), nn.Linear(hidden, n)]
+    theta = torch.randn(model.quantum_layer.params.numel()) * 0.1
+    post = [nn.Linear(n, hidden), nn.Linear(hidden, 1)]
+    for layer in pre + post:
+        nn.init.xavier_normal_(layer.weight)
+        nn.init.zeros_(layer.bias)
+    with torch.no_grad():
+        for dst, src in ((model.preprocessor[0], pre[0]), (model.preprocessor[2], pre[1]),
+                         (model.postprocessor[0], post[0]), (model.postprocessor[2], post[1])):
+            dst.weight.copy_(src.weight)
+            dst.bias.copy_(src.bias)
+        model.quantum_layer.params.copy_(theta.reshape(model.quantum_layer.params.shape))
+
+
+def twin_sample(batch_size, device=None):
+    """IC -> residual -> the four boundary faces (train_hybrid_qpinn.py:686-697)."""
+    X_ic = sample_box(TWIN_BOX_IC, batch_size // 3, device)
+    X_res = sample_box(BOX_DOM, batch_size, device)
+    X_bc = torch.cat([sample_box(b, batch_size // 12, device) for b in TWIN_BOX_BC], 0)
+    return X_ic, X_bc, X_res
+
+
+def twin_loss_on_batches(model, X_ic, X_bc, X_res, D=0.01):
+    """:704-719 — u on IC, u on BC (target 0), residual u_t - D (u_xx + u_yy) (target 0); 2, 4, 2 weights."""
+    u_ic = model.forward(X_ic)
+    u_bc = model.forward(X_bc)
+    t, x, y = X_res[:, 0:1], X_res[:, 1:2], X_res[:, 2:3]
+    _, r_pred = diffusion_residual(model, t, x, y, D=D, vx=0.0, vy=0.0)
+    l_ic = model.loss_fn(u_ic, twin_analytic_u(X_ic, D))
+    l_bc = model.loss_fn(u_bc, torch.zeros_like(u_bc))
+    l_r = model.loss_fn(r_pred, torch.zeros_like(r_pred))
+    return 2.0 * l_r + 4.0 * l_bc + 2.0 * l_ic, l_r, l_bc, l_ic
+
+
+def twin_train_step(model, batch_size, batches=None, D=0.01):
+    """One epoch of train_hybrid_qpinn.py:680-735."""
+    model.optimizer.zero_grad()
+    X_ic, X_bc, X_res = twin_sample(batch_size, model.device) if batches is None else batches
+    loss, l_r, l_bc, l_ic = twin_loss_on_batches(model, X_ic, X_bc, X_res, D)
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0)
+    model.optimizer.step()
+    model.scheduler.step(loss)
+    model.loss_history.append(loss.item())
+    return loss.item(), l_r.item(), l_bc.item(), l_ic.item()

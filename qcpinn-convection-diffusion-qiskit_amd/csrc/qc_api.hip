@@ -10,6 +10,8 @@
 #include <mutex>
 
 static_assert(sizeof(QcPde) == sizeof(qc_pde), "qc_pde layout");
+static_assert(QC_PB_CONVECTION_DIFFUSION == QC_PROBLEM_CONVECTION_DIFFUSION && QC_PB_PURE_DIFFUSION == QC_PROBLEM_PURE_DIFFUSION,
+              "problem ids");
 static_assert(sizeof(QcOptHyper) == sizeof(qc_opt_hyper), "qc_opt_hyper layout");
 
 static thread_local int g_last_hip = 0;
@@ -354,12 +356,18 @@ int qc_adam_step(float* flat, int NP, float* prm, float* m, float* v, void* stat
   return after_launch();
 }
 
+int qc_sample_collocation_faces(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
+                                int64_t n_bc, int64_t off_bc, int64_t bc_face_points, uint64_t seed, uint64_t step,
+                                void* stream) {
+  if (n_res < 0 || n_ic < 0 || n_bc < 0 || off_res < 0 || off_ic < 0 || off_bc < 0 || bc_face_points < 0) return QC_ERR_ARG;
+  if ((n_res > 0 && !X_res) || (n_ic + n_bc > 0 && !X_val)) return QC_ERR_ARG;
+  qc_sample_launch(X_res, n_res, off_res, X_val, n_ic, off_ic, n_bc, off_bc, bc_face_points, seed, step, (hipStream_t)stream);
+  return after_launch();
+}
+
 int qc_sample_collocation(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
                           int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, void* stream) {
-  if (n_res < 0 || n_ic < 0 || n_bc < 0 || off_res < 0 || off_ic < 0 || off_bc < 0) return QC_ERR_ARG;
-  if ((n_res > 0 && !X_res) || (n_ic + n_bc > 0 && !X_val)) return QC_ERR_ARG;
-  qc_sample_launch(X_res, n_res, off_res, X_val, n_ic, off_ic, n_bc, off_bc, seed, step, (hipStream_t)stream);
-  return after_launch();
+  return qc_sample_collocation_faces(X_res, n_res, off_res, X_val, n_ic, off_ic, n_bc, off_bc, 0, seed, step, stream);
 }
 
 int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream) {
@@ -392,9 +400,9 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
   }
 
   if (phases & QC_PHASE_SAMPLE) {
-    if ((rc = qc_sample_collocation((float*)d->X_res_dev, d->B_res, d->sample_off_res, (float*)d->X_val_dev, d->n_ic,
-                                    d->sample_off_ic, d->B_val - d->n_ic, d->sample_off_bc, d->sample_seed,
-                                    d->sample_step, st))) return rc;
+    if ((rc = qc_sample_collocation_faces((float*)d->X_res_dev, d->B_res, d->sample_off_res, (float*)d->X_val_dev, d->n_ic,
+                                          d->sample_off_ic, d->B_val - d->n_ic, d->sample_off_bc,
+                                          d->sample_bc_face_points, d->sample_seed, d->sample_step, st))) return rc;
   }
   if (phases & QC_PHASE_GRADS) {
     // the two pipelines are independent until the row reduction: fork the value pipeline onto a side

@@ -24,12 +24,15 @@ inline QcLayout qc_layout(int H, int n, int n_theta) {
   return L;
 }
 
+constexpr int QC_PB_CONVECTION_DIFFUSION = 0, QC_PB_PURE_DIFFUSION = 1;   // == QC_PROBLEM_* of the public header
+
 struct QcPde {  // == qc_pde of the public header
   float D, vx, vy;
   float w_res;
   float inv_n_res;
   float w_val_a, w_val_b;
   float inv_n_a, inv_n_b;
+  int problem;
   int64_t n_seg_a;
 };
 
@@ -88,7 +91,7 @@ int qc_opt_adam(float* flat, int NP, float* prm, float* m, float* v, QcOptState*
                 float* hist, int hist_cap, const qc_program* pg, int theta_off, QcTrig* trig, hipStream_t);
 int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t);
 int qc_sample_launch(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
-                     int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, hipStream_t);
+                     int64_t n_bc, int64_t off_bc, int64_t bc_face_points, uint64_t seed, uint64_t step, hipStream_t);
 size_t qc_hbm_workspace_bytes(const qc_program* pg, int nch, bool backward);
 int qc_hbm_forward(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
                    int64_t B, int nch, void* ws, size_t ws_bytes, hipStream_t);

@@ -42,6 +42,13 @@ __device__ __forceinline__ float analytic_r(float t, float x, float y, float D, 
   return ut + vx * ux + vy * uy - D * (uxx + uyy);
 }
 
+// second workload (train_hybrid_qpinn.py:116-131): u = sin(pi x) sin(pi y) exp(-2 pi^2 D t); its PDE
+// u_t = D (u_xx + u_yy) has no forcing term, and u vanishes on the four boundary faces
+__device__ __forceinline__ float analytic_u_diffusion(float t, float x, float y, float D) {
+  const float pi = 3.14159265358979323846f;
+  return sinf(pi * x) * sinf(pi * y) * expf(-2.f * pi * pi * D * t);
+}
+
 // ================================================================== pre network, forward jets
 // Block = 4 waves on ONE 64-point tile: lane = collocation point, wave w takes a quarter of the
 // hidden units (wave-uniform weights -> scalar loads); the four partial angle jets meet in LDS.
@@ -327,7 +334,8 @@ __global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const
       const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
       float* row = part + (row0 + tile) * part_stride;
       if constexpr (NCH == 6) {
-        const float e = live ? res - analytic_r(t, x, y, pde.D, pde.vx, pde.vy) : 0.f;
+        const float target = pde.problem == QC_PB_PURE_DIFFUSION ? 0.f : analytic_r(t, x, y, pde.D, pde.vx, pde.vy);
+        const float e = live ? res - target : 0.f;
         gsc = pde.w_res * e;
         if (wave == 0) {
           const float ls = qc_wave_sum_to_lane63(e * e * pde.inv_n_res);
@@ -339,7 +347,10 @@ __global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const
         }
       } else {
         const bool seg_a = p < pde.n_seg_a;
-        const float e = live ? u[0] - analytic_u(t, x, y) : 0.f;
+        const float target = pde.problem == QC_PB_PURE_DIFFUSION
+                                 ? (seg_a ? analytic_u_diffusion(t, x, y, pde.D) : 0.f)
+                                 : analytic_u(t, x, y);
+        const float e = live ? u[0] - target : 0.f;
         ub0 = (seg_a ? pde.w_val_a : pde.w_val_b) * e;
         if (wave == 0) {
           const float la = qc_wave_sum_to_lane63(seg_a ? e * e * pde.inv_n_a : 0.f);

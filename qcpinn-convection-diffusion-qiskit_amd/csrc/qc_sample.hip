@@ -27,10 +27,13 @@ __device__ __forceinline__ U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 
 __device__ __forceinline__ float u01(uint32_t v) { return (float)(v >> 8) * (1.0f / 16777216.0f); }  // [0,1)
 
-// segment 0: residual points in [0,1]^3; 1: IC points (t = 0); 2: BC1 points (x = 0)
+// segment 0: residual points in [0,1]^3; 1: IC points (t = 0); 2: boundary points: the x = 0 face
+// (trainer/diffusion_train.py:13-16), or with face_pts > 0 the four faces x=0, x=1, y=0, y=1 of the second
+// workload (train_hybrid_qpinn.py:166-176), face = global index / face_pts
 __global__ void __launch_bounds__(256) k_sample(float* __restrict__ X_res, int64_t n_res, int64_t off_res,
                                                 float* __restrict__ X_val, int64_t n_ic, int64_t off_ic,
-                                                int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step) {
+                                                int64_t n_bc, int64_t off_bc, int64_t face_pts, uint64_t seed,
+                                                uint64_t step) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   int seg;
   int64_t local, gidx;
@@ -47,8 +50,14 @@ __global__ void __launch_bounds__(256) k_sample(float* __restrict__ X_res, int64
   const U4 ctr = {(uint32_t)gidx, (uint32_t)(gidx >> 32), (uint32_t)step, (uint32_t)(step >> 32) ^ ((uint32_t)seg << 30)};
   const U4 r = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
   const float t = seg == 1 ? 0.f : u01(r.x);
-  const float x = seg == 2 ? 0.f : u01(r.y);
-  const float y = u01(r.z);
+  float x = u01(r.y), y = u01(r.z);
+  if (seg == 2) {
+    const int64_t face = face_pts > 0 ? gidx / face_pts : 0;
+    if (face == 0) x = 0.f;
+    else if (face == 1) x = 1.f;
+    else if (face == 2) y = 0.f;
+    else y = 1.f;
+  }
   dst[0] = t;
   dst[1] = x;
   dst[2] = y;
@@ -57,10 +66,10 @@ __global__ void __launch_bounds__(256) k_sample(float* __restrict__ X_res, int64
 }  // namespace
 
 int qc_sample_launch(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
-                     int64_t n_bc, int64_t off_bc, uint64_t seed, uint64_t step, hipStream_t st) {
+                     int64_t n_bc, int64_t off_bc, int64_t bc_face_points, uint64_t seed, uint64_t step, hipStream_t st) {
   const int64_t total = n_res + n_ic + n_bc;
   if (total <= 0) return QC_OK;
   hipLaunchKernelGGL(k_sample, dim3(qc_ceil_div(total, 256)), dim3(256), 0, st, X_res, n_res, off_res, X_val, n_ic,
-                     off_ic, n_bc, off_bc, seed, step);
+                     off_ic, n_bc, off_bc, bc_face_points, seed, step);
   return QC_OK;
 }

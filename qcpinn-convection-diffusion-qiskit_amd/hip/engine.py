@@ -197,13 +197,14 @@ class SolverEngine:
             raise L.QcError(f"flat parameter vector has {flat_params.numel()} entries, layout needs {self.NP}")
         self.flat = _need(flat_params, self.device, "flat params")
         self.D, self.vx, self.vy = float(D), float(vx), float(vy)
+        self.problem = L.QC_PROBLEM_CONVECTION_DIFFUSION      # analytic targets of the fused loss (qcpinn_hip.h)
         self._fused: Dict[Tuple[int, int, int], "FusedStep"] = {}
 
     # ------------------------------------------------------------------ helpers
     def _pde(self, n_res=1, n_ic=1, n_bc=1, n_seg_a=0) -> L.QcPde:
         # loss = 2*MSE_res + 4*MSE_bc + 2*MSE_ic (trainer/diffusion_train.py:47); d/d(err) = 2*w/N * err
         return L.QcPde(self.D, self.vx, self.vy, 4.0 / n_res, 1.0 / n_res, 4.0 / n_ic, 8.0 / n_bc,
-                       1.0 / n_ic, 1.0 / n_bc, n_seg_a)
+                       1.0 / n_ic, 1.0 / n_bc, self.problem, n_seg_a)
 
     def refresh_gates(self) -> None:
         self.circuit.prepare(self.flat[self.theta_off: self.theta_off + self.n_theta])
@@ -277,7 +278,7 @@ class SolverEngine:
 
     # ------------------------------------------------------------------ fused training step
     def fused(self, B_res: int, n_ic: int, n_bc: int, opt: "OptimState", counts=None) -> "FusedStep":
-        key = (B_res, n_ic, n_bc, id(opt), counts)
+        key = (B_res, n_ic, n_bc, id(opt), counts, self.problem, self.D, self.vx, self.vy)
         if key not in self._fused:
             self._fused[key] = FusedStep(self, B_res, n_ic, n_bc, opt, counts)
         return self._fused[key]
@@ -367,12 +368,16 @@ class FusedStep:
         d.n_ic = n_ic
         d.sample_off_res = d.sample_off_ic = d.sample_off_bc = 0
         d.sample_seed, d.sample_step = 0, 0
+        d.sample_bc_face_points = 0
         self.desc = d
 
-    def set_sampler(self, seed: int, off_res: int = 0, off_ic: int = 0, off_bc: int = 0) -> None:
+    def set_sampler(self, seed: int, off_res: int = 0, off_ic: int = 0, off_bc: int = 0,
+                    bc_face_points: int = 0) -> None:
         """On-device batches (QC_PHASE_SAMPLE): Philox stream `seed`; off_* = global index of this
-        rank's first point in each batch (data parallelism)."""
+        rank's first point in each batch (data parallelism); bc_face_points > 0 spreads the boundary
+        batch over the four faces x=0, x=1, y=0, y=1 (that many GLOBAL points per face)."""
         d = self.desc
+        d.sample_bc_face_points = bc_face_points
         d.sample_seed = seed & 0xFFFFFFFFFFFFFFFF
         d.sample_off_res, d.sample_off_ic, d.sample_off_bc = off_res, off_ic, off_bc
 

@@ -23,8 +23,11 @@ EXPORTS = (
     "qc_trig_bytes", "qc_program_set_encoding", "qc_amp_forward", "qc_amp_backward", "qc_prepare_gates",
     "qc_circuit_workspace_bytes", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_forward_jets_keep", "qc_backward_jets_kept", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
-    "qc_sample_collocation", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
+    "qc_sample_collocation", "qc_sample_collocation_faces", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
 )
+
+
+QC_PROBLEM_CONVECTION_DIFFUSION, QC_PROBLEM_PURE_DIFFUSION = 0, 1      # qc_pde.problem
 
 
 class QcError(RuntimeError):
@@ -34,7 +37,7 @@ class QcError(RuntimeError):
 class QcPde(C.Structure):
     _fields_ = [("D", C.c_float), ("vx", C.c_float), ("vy", C.c_float), ("w_res", C.c_float),
                 ("inv_n_res", C.c_float), ("w_val_a", C.c_float), ("w_val_b", C.c_float),
-                ("inv_n_a", C.c_float), ("inv_n_b", C.c_float), ("n_seg_a", C.c_int64)]
+                ("inv_n_a", C.c_float), ("inv_n_b", C.c_float), ("problem", C.c_int), ("n_seg_a", C.c_int64)]
 
 
 class QcOptHyper(C.Structure):
@@ -61,6 +64,7 @@ class QcStepDesc(C.Structure):
         ("pde", QcPde), ("hyper", QcOptHyper),
         ("n_ic", C.c_int64), ("sample_off_res", C.c_int64), ("sample_off_ic", C.c_int64),
         ("sample_off_bc", C.c_int64), ("sample_seed", C.c_uint64), ("sample_step", C.c_uint64),
+        ("sample_bc_face_points", C.c_int64),
         ("circ_ws_dev", C.c_void_p), ("circ_ws_bytes", C.c_size_t),
     ]
 

@@ -10,8 +10,11 @@ chain, see ``DVPDESolver.residual``); the returned tensors are attached to the a
 callable model (the reference's duck type, e.g. a classical solver) goes through the generic
 autograd formulation below, which is the reference's algorithm.
 
-The other operators of the reference file (Navier-Stokes, Klein-Gordon, wave, Helmholtz) are not
-used by the DV trainers and are out of scope.
+The other operators of the reference file (nn/pde.py:2-52,73-95: Navier-Stokes 2-D, Klein-Gordon,
+wave, Helmholtz) are provided in the same autograd formulation, with the reference's signatures,
+constants and return shapes.  None of the DV trainers uses them; they run on any model, including
+user-composed models around ``DVQuantumLayer`` (whose ``create_graph=True`` reverse pass supplies the
+second derivatives).  Fused derivative-channel kernels for them are not built.
 """
 import torch
 
@@ -42,3 +45,61 @@ def diffusion_operator(model, t, x, y, sigma_t=1.0, sigma_x=1.0, sigma_y=1.0, D=
     u_xx = _grad(u_x, x) / sigma_x
     u_yy = _grad(u_y, y) / sigma_y
     return u, u_t + v_x * u_x + v_y * u_y - D * (u_xx + u_yy)
+
+
+def _track(*coords):
+    for c in coords:
+        c.requires_grad_(True)      # the reference sets .requires_grad = True on its inputs as well
+
+
+def _second(out, wrt):
+    first = _grad(out, wrt)
+    return first, _grad(first, wrt)
+
+
+def navier_stokes_2D_operator(model, t, x, y, min_x=0, max_x=1):
+    """Reference nn/pde.py:2-27.  model: (B,3) -> (B,3) = (u, v, p); returns [continuity, f_u, f_v]
+    with viscosity 0.00345 and density 1056 (the reference's constants)."""
+    viscosity, density = 0.00345, 1056.0
+    _track(t, x, y)
+    fields = model(torch.cat((t, x, y), 1))
+    u, v, p = fields[:, 0:1], fields[:, 1:2], fields[:, 2:3]
+    mom = []
+    for w, p_k in ((u, _grad(p, x)), (v, _grad(p, y))):
+        w_t = _grad(w, t)
+        w_x, w_xx = _second(w, x)
+        w_y, w_yy = _second(w, y)
+        mom.append((w_x, w_y, w_t + (u * w_x + v * w_y) + p_k / density - viscosity * (w_xx + w_yy)))
+    (u_x, _, f_u), (_, v_y, f_v) = mom
+    return [u_x + v_y, f_u, f_v]
+
+
+def klein_gordon_operator(fluid_model, t, x, x_min=0.0, x_max=1.0):
+    """Reference nn/pde.py:28-41: u_tt - u_xx + 0*u + u^3; returns (u, residual)."""
+    alpha, beta, gamma, power = -1.0, 0.0, 1.0, 3
+    _track(t, x)
+    u = fluid_model(torch.cat((t, x), 1))
+    _, u_tt = _second(u, t)
+    _, u_xx = _second(u, x)
+    return u, u_tt + alpha * u_xx + beta * u + gamma * u ** power
+
+
+def wave_operator(model, t, x, sigma_t=1.0, sigma_x=1.0):
+    """Reference nn/pde.py:42-52: u_tt - c^2 u_xx with c = 2 (the sigma arguments are accepted and, as in
+    the reference, unused); returns (u, residual)."""
+    speed = 2
+    _track(t, x)
+    u = model(torch.cat((t, x), 1))
+    _, u_tt = _second(u, t)
+    _, u_xx = _second(u, x)
+    return u, u_tt - speed ** 2 * u_xx
+
+
+def helmholtz_operator(fluid_model, x1, x2):
+    """Reference nn/pde.py:73-95: u_x1x1 + u_x2x2 + lambda*u with lambda = 1; returns [u, residual]."""
+    lam = 1.0
+    _track(x1, x2)
+    u = fluid_model(torch.cat((x1, x2), 1))
+    _, u_11 = _second(u, x1)
+    _, u_22 = _second(u, x2)
+    return [u, u_11 + u_22 + lam * u]

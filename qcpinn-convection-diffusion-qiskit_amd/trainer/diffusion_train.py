@@ -72,18 +72,30 @@ class FusedTrainer:
     ``torch.manual_seed`` still controls the run); ``sampler="torch"`` uses three ``torch.rand`` calls
     like the reference (IC -> BC -> residual)."""
 
-    def __init__(self, model, batch_size: int, capacity: int, sampler: str = "device"):
+    def __init__(self, model, batch_size: int, capacity: int, sampler: str = "device", *, n_bc: int = None,
+                 bc_faces: int = 1, pde: dict = None):
+        """``n_bc`` (default ``batch_size // 3``): GLOBAL boundary points per step; ``bc_faces`` = 4 spreads them
+        evenly over the faces x=0, x=1, y=0, y=1 (second workload, train_hybrid_qpinn.py:689-697) instead of
+        the x=0 face; ``pde`` = {"D", "vx", "vy", "problem"} overrides the engine's operator / targets."""
         dev = model._resolve_device(model.device)
         if dev is None or dev.type != "cuda":
             raise _lib.QcError("training a DVPDESolver needs a GPU (HIP kernels, no CPU fallback)")
         self.model, self.device = model, dev
         self.eng = model._engine_for(dev)
+        if pde:
+            self.eng.D, self.eng.vx, self.eng.vy = float(pde["D"]), float(pde["vx"]), float(pde["vy"])
+            self.eng.problem = int(pde["problem"])
         self.world, self.rank = _dist_info()
         n3 = batch_size // 3
-        self.global_counts = (batch_size, n3, n3)                    # residual, IC, BC
+        nb = n3 if n_bc is None else int(n_bc)
+        if bc_faces not in (1, 4) or (bc_faces == 4 and nb % 4):
+            raise ValueError("bc_faces must be 1 or 4 (with n_bc divisible by 4)")
+        self.bc_face_points = nb // 4 if bc_faces == 4 else 0
+        self.global_counts = (batch_size, n3, nb)                    # residual, IC, BC
         self.B_res = shard_count(batch_size, self.world, self.rank)
         self.n_ic = shard_count(n3, self.world, self.rank)
-        self.n_bc = shard_count(n3, self.world, self.rank)
+        self.n_bc = shard_count(nb, self.world, self.rank)
+        self.bc_start = shard_slice(nb, self.world, self.rank).start
         self.opt = self._make_opt_state(capacity)
         self.fs = self.eng.fused(self.B_res, self.n_ic, self.n_bc, self.opt, self.global_counts)
         self.lo = {k: box(k, dev)[0:1] for k in ("ics", "bc1", "dom")}
@@ -101,8 +113,7 @@ class FusedTrainer:
             dist.broadcast(t, 0)
             seed = int(t.item())
         self.fs.set_sampler(seed, shard_slice(batch_size, self.world, self.rank).start,
-                            shard_slice(n3, self.world, self.rank).start,
-                            shard_slice(n3, self.world, self.rank).start)
+                            shard_slice(n3, self.world, self.rank).start, self.bc_start, self.bc_face_points)
 
     # -- optimiser state: continue from the torch optimiser / scheduler objects of the model
     def _make_opt_state(self, capacity):
@@ -159,8 +170,13 @@ class FusedTrainer:
         if self.n_ic:
             fs.X_val[: self.n_ic] = self.lo["ics"] + self.span["ics"] * torch.rand(self.n_ic, 3, device=dev)
         if self.n_bc:
-            fs.X_val[self.n_ic: self.n_ic + self.n_bc] = self.lo["bc1"] + self.span["bc1"] * torch.rand(
-                self.n_bc, 3, device=dev)
+            pts = self.lo["bc1"] + self.span["bc1"] * torch.rand(self.n_bc, 3, device=dev)
+            if self.bc_face_points:      # faces x=0, x=1, y=0, y=1 by GLOBAL boundary-point index
+                pts = torch.rand(self.n_bc, 3, device=dev)
+                face = (self.bc_start + torch.arange(self.n_bc, device=dev)) // self.bc_face_points
+                pts[:, 1] = torch.where(face == 0, 0.0, torch.where(face == 1, 1.0, pts[:, 1]))
+                pts[:, 2] = torch.where(face == 2, 0.0, torch.where(face == 3, 1.0, pts[:, 2]))
+            fs.X_val[self.n_ic: self.n_ic + self.n_bc] = pts
         if self.B_res:
             fs.X_res[: self.B_res] = self.lo["dom"] + self.span["dom"] * torch.rand(self.B_res, 3, device=dev)
 

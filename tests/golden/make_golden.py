@@ -5,7 +5,9 @@ What is pinned by the *reference's own code* (imported from /root/reference, nev
   * ``analytic.npz``  — data/diffusion_dataset.py ``u`` and ``r`` on a fixed batch;
   * ``operator_*.npz`` — nn/pde.py ``diffusion_operator`` driving the oracle-backed solver;
   * ``train_*.npz``   — trainer/diffusion_train.py ``train`` driving the oracle-backed solver
-    (loss history, final weights), plus the batches its RNG produced.
+    (loss history, final weights), plus the batches its RNG produced;
+  * ``other_operators.npz`` — nn/pde.py Navier-Stokes / Klein-Gordon / wave / Helmholtz operators driving an
+    oracle-backed composite model (``python tests/golden/make_golden.py operators``).
 What is NOT pinned by the reference (PennyLane is absent here, the reference has no fixtures):
   * ``expval_*.npz``  — oracle <Z> vectors; they freeze the oracle against later drift and are the
     GPU parity targets, but stay "parity unpinned" w.r.t. PennyLane itself.
@@ -167,6 +169,53 @@ def make_train(tag, args, batch_size):
              batch_size=np.array(batch_size), **init, **final)
 
 
+class OracleComposite(torch.nn.Module):
+    """A user-style model around the quantum layer: Linear(d_in,H)-Tanh-Linear(H,n) -> <Z> -> Linear(n,H)-Tanh-
+    Linear(H,d_out) (the arithmetic of nn/DVPDESolver.py:81-110 with free input/output widths)."""
+
+    def __init__(self, args, d_in, d_out, hidden=16):
+        super().__init__()
+        n = args["num_qubits"]
+        self.pre = torch.nn.Sequential(torch.nn.Linear(d_in, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, n))
+        self.q = osol.OracleQuantumLayer(args)
+        self.post = torch.nn.Sequential(torch.nn.Linear(n, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, d_out))
+        self.n = n
+
+    def forward(self, X):
+        q = self.q(self.pre(X)).to(torch.float32)
+        return self.post(q.T.reshape(-1, self.n))
+
+
+def make_other_operators():
+    """nn/pde.py:2-52,73-95 of the REFERENCE (imported) driving an oracle-backed composite model: outputs,
+    a scalar loss on them and its parameter gradient."""
+    args = base_args(q_ansatz="cascade", num_qubits=4)
+    out = {}
+    cases = [("navier_stokes", ref_pde.navier_stokes_2D_operator, 3, 3), ("klein_gordon", ref_pde.klein_gordon_operator, 2, 1),
+             ("wave", ref_pde.wave_operator, 2, 1), ("helmholtz", ref_pde.helmholtz_operator, 2, 1)]
+    for k, (name, fn, d_in, d_out) in enumerate(cases):
+        torch.manual_seed(20 + k)
+        model = OracleComposite(args, d_in, d_out)
+        X = torch.rand(24, d_in, generator=torch.Generator().manual_seed(50 + k), dtype=torch.float32)
+        cols = [X[:, i:i + 1].clone() for i in range(d_in)]
+        res = fn(model, *cols)
+        res = list(res)
+        loss = sum((r ** 2).mean() * (i + 1) for i, r in enumerate(res))
+        model.zero_grad()
+        loss.backward()
+        out[f"{name}__X"] = X.numpy()
+        for i, r in enumerate(res):
+            out[f"{name}__out{i}"] = r.detach().numpy()
+        out[f"{name}__loss"] = np.array(loss.item())
+        out[f"{name}__grad"] = flat_grads(model)
+        out.update(state_arrays(model, f"{name}__w__"))
+    np.savez(os.path.join(HERE, "other_operators.npz"), **out)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "operators":
+    make_other_operators()
+    sys.exit(0)
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "n16":
     # the 16-qubit cross_mesh model of BASELINE config 5 (2 221 parameters), tiny batches
     a16 = base_args(num_qubits=16, q_ansatz="cross_mesh")
@@ -184,3 +233,4 @@ if __name__ == "__main__":
     make_train("cascade_n4_b64", base_args(epochs=20), 64)
     make_train("cascade_n4_b128", base_args(epochs=8), 128)
     make_train("layered_n8_b32", base_args(epochs=5, num_qubits=8, num_quantum_layers=2, q_ansatz="layered"), 32)
+    make_other_operators()
