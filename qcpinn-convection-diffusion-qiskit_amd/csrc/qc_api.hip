@@ -116,7 +116,8 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   }
   p->n_qubits = n_qubits; p->n_gates = n_gates; p->n_params = n_params; p->n_u4 = n_u4;
   p->h_gates = h; p->d_gates = nullptr;
-  p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p) : -1;
+  p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p)
+                 : ((n_qubits >= 6 && n_qubits <= 8) ? qc_wave_match_static(p) : -1);
   p->hbm_plan = nullptr;
   p->amplitude = 0;
   p->lead_rx = n_gates >= n_qubits ? 1 : 0;   // RX(p_w) right after the embedding RX(a_w), wire by wire, distinct slots

@@ -577,21 +577,46 @@ __global__ void __launch_bounds__(256) k_hbm_diag_w(const Cplx* __restrict__ st,
   wp[(size_t)grp * N + k] = acc;
 }
 
-// one block per diagonal gate: acc[slot] += sum_k g(k) * sum_grp wp[grp][k],  g = +-1 (target bit), 0 if control clear
-__global__ void __launch_bounds__(256) k_hbm_diag_grad(const QcDiagGate* __restrict__ dg, const float* __restrict__ wp,
-                                                       int n, int groups, float* __restrict__ acc) {
+// W[k] = sum_grp wp[grp][k], written over group 0 (the other group rows become scratch for the gate partials)
+__global__ void __launch_bounds__(256) k_hbm_diag_collapse(float* __restrict__ wp, int n, int groups) {
+  const int64_t N = (int64_t)1 << n;
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  float w = 0.f;
+  for (int q = 0; q < groups; ++q) w += wp[(size_t)q * N + k];
+  wp[k] = w;
+}
+
+// block (gate, chunk): gp[gate][chunk] = sum over the chunk's k of g(k) * W[k],  g = +-1 (target bit), 0 if the
+// control bit is clear.  (One block per gate walking all 2^n entries was latency-bound: 0.77 ms per diagonal run
+// at n = 16; 16 chunks per gate fill the chip.)
+constexpr int DIAG_CHUNKS = 16;
+__global__ void __launch_bounds__(256) k_hbm_diag_grad(const QcDiagGate* __restrict__ dg, const float* __restrict__ W,
+                                                       int n, float* __restrict__ gp) {
   __shared__ float s_red[4];
   const QcDiagGate g = dg[blockIdx.x];
   const int64_t N = (int64_t)1 << n;
+  const int64_t per = (N + DIAG_CHUNKS - 1) / DIAG_CHUNKS;
+  const int64_t k0 = (int64_t)blockIdx.y * per, k1 = (k0 + per) < N ? (k0 + per) : N;
   float t = 0.f;
-  for (int64_t k = threadIdx.x; k < N; k += 256) {
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
     if (g.bc >= 0 && !((k >> g.bc) & 1)) continue;
-    float w = 0.f;
-    for (int q = 0; q < groups; ++q) w += wp[(size_t)q * N + k];
+    const float w = W[k];
     t += ((k >> g.bt) & 1) ? -w : w;
   }
   const float tot = block_sum_256(t, s_red);
-  if (threadIdx.x == 0) acc[g.slot] += tot;
+  if (threadIdx.x == 0) gp[(size_t)blockIdx.x * DIAG_CHUNKS + blockIdx.y] = tot;
+}
+
+// acc[slot_i] += gp[i][0] + ... + gp[i][DIAG_CHUNKS-1], in order
+__global__ void __launch_bounds__(256) k_hbm_diag_fold(const QcDiagGate* __restrict__ dg, int ng, const float* __restrict__ gp,
+                                                       float* __restrict__ acc) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= ng) return;
+  float t = 0.f;
+#pragma unroll
+  for (int c = 0; c < DIAG_CHUNKS; ++c) t += gp[(size_t)i * DIAG_CHUNKS + c];
+  acc[dg[i].slot] += t;
 }
 
 struct Ws {
@@ -846,7 +871,10 @@ static void staged_backward(const qc_program* pg, const QcTrig* trig, const floa
   const int64_t N = (int64_t)1 << n;
   auto diag_grads = [&](const QcStage& d) {   // memory holds chi, lam at the OUTPUT of the diagonal run d
     hipLaunchKernelGGL(k_hbm_diag_w, dim3(qc_ceil_div(N, 256), W_GROUPS), dim3(256), 0, st, w.chi, S, n, W_GROUPS, w.wpart);
-    hipLaunchKernelGGL(k_hbm_diag_grad, dim3(d.ng), dim3(256), 0, st, plan->d_dgates + d.g0, w.wpart, n, W_GROUPS, w.acc);
+    // (the gate partials live in group rows 1.. of wpart, free after the collapse: needs ng * 16 <= 15 * 2^n)
+    hipLaunchKernelGGL(k_hbm_diag_collapse, dim3(qc_ceil_div(N, 256)), dim3(256), 0, st, w.wpart, n, W_GROUPS);
+    hipLaunchKernelGGL(k_hbm_diag_grad, dim3(d.ng, DIAG_CHUNKS), dim3(256), 0, st, plan->d_dgates + d.g0, w.wpart, n, w.wpart + N);
+    hipLaunchKernelGGL(k_hbm_diag_fold, dim3(qc_ceil_div(d.ng, 256)), dim3(256), 0, st, plan->d_dgates + d.g0, d.ng, w.wpart + N, w.acc);
   };
   for (int i = plan->n_stages - 1; i >= 0; --i) {
     const QcStage& sd = plan->stages[i];

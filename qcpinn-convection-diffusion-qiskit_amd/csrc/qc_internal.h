@@ -68,6 +68,7 @@ int qc_reg_jets_bwd(const qc_program*, const QcTrig*, const float* umat, const f
                     float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, const float* chi_store,
                     hipStream_t);
 size_t qc_reg_chi_store_bytes(const qc_program* pg, int64_t B);
+int qc_wave_match_static(const qc_program*);
 int qc_wave_value_fwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, float* expval,
                       int64_t B, hipStream_t);
 int qc_wave_value_bwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, const float* cot,
