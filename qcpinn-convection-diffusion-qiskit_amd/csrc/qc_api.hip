@@ -159,6 +159,13 @@ int qc_program_destroy(qc_program* p) {
 int qc_program_set_encoding(qc_program* p, int amplitude) {
   if (!p || (amplitude != 0 && amplitude != 1)) return QC_ERR_ARG;
   if (amplitude && ((int64_t)1 << p->n_qubits) < p->n_qubits) return QC_ERR_ARG;
+  if (p->amplitude != amplitude && p->hbm_plan) {   // the staged plan folds the leading RX layer only for angle encoding
+    p->amplitude = amplitude;
+    QcHbmPlan* fresh = qc_hbm_plan_create(p);
+    if (!fresh) return QC_ERR_ALLOC;
+    qc_hbm_plan_destroy((QcHbmPlan*)p->hbm_plan);
+    p->hbm_plan = fresh;
+  }
   p->amplitude = amplitude;
   return QC_OK;
 }
@@ -195,8 +202,11 @@ size_t qc_circuit_workspace_bytes(const qc_program* p, int nch, int backward) {
   return qc_hbm_workspace_bytes(p, nch, backward != 0);
 }
 
+static size_t hbm_base_bytes(const qc_program* p) { return (qc_hbm_workspace_bytes(p, 6, true) + 255) & ~(size_t)255; }
 static size_t step_circuit_bytes(const qc_program* p, int64_t B_res) {
-  if (use_hbm(p->n_qubits)) return qc_hbm_workspace_bytes(p, 6, true);
+  // n >= 9: the per-tile scratch, plus (when it fits the budget) one [chi | lam] slot per residual tile so the
+  // adjoint pass of the step starts from the forward pass's final states instead of recomputing them
+  if (use_hbm(p->n_qubits)) return hbm_base_bytes(p) + qc_hbm_keep_bytes(p, B_res);
   if (use_reg(p->n_qubits)) return qc_reg_chi_store_bytes(p, B_res);   // optional: enables the no-recompute adjoint
   return 0;
 }
@@ -439,12 +449,21 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if ((rc = qc_pre_forward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->ajets_res_dev, d->B_res, 6, st))) return rc;
       // register family: keep the final states of the forward pass for the adjoint kernel of this step
       float* chi_store = (use_reg(n) && cws && cws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res)) ? (float*)cws : nullptr;
+      // HBM family: per-tile kept-state store behind the per-tile scratch (present iff the caller's workspace has room)
+      void* hbm_store = nullptr;
+      if (use_hbm(n) && cws && qc_hbm_keep_bytes(d->prog, d->B_res) > 0 &&
+          cws_bytes >= hbm_base_bytes(d->prog) + qc_hbm_keep_bytes(d->prog, d->B_res))
+        hbm_store = (char*)cws + hbm_base_bytes(d->prog);
       if (amp && (rc = qc_amp_forward(d->ajets_res_dev, u_res, n, d->B_res, 6, st))) return rc;
       const float* cin_res = amp ? u_res : d->ajets_res_dev;
       float* cout_res = amp ? ub_res : d->abar_res_dev;
       if (use_reg(n)) {
         if ((rc = qc_reg_jets_fwd(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, chi_store, st)))
           return rc;
+        if ((rc = after_launch())) return rc;
+      } else if (hbm_store) {
+        if ((rc = qc_hbm_forward_keep(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, cws, hbm_base_bytes(d->prog),
+                                      hbm_store, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, cws, cws_bytes, st)))
         return rc;
@@ -455,6 +474,10 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (use_reg(n)) {
         if ((rc = qc_reg_jets_bwd(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res,
                                   d->part_dev + L.oTh, d->part_stride, 0, d->B_res, chi_store, st))) return rc;
+        if ((rc = after_launch())) return rc;
+      } else if (hbm_store) {
+        if ((rc = qc_hbm_backward_kept(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,
+                                       d->part_stride, 0, d->B_res, cws, hbm_base_bytes(d->prog), hbm_store, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res,
                                         d->part_dev + L.oTh, d->part_stride, 0, d->B_res, cws, cws_bytes, st))) return rc;

@@ -32,13 +32,14 @@ struct Cplx {
 // ---------------------------------------------------------------- per-point, per-wire embedding data
 template <int NCH>
 __global__ void k_hbm_wiredata(const float* __restrict__ ajets, int64_t B, int64_t p0, int T, int n,
-                               float* __restrict__ wd) {
+                               float* __restrict__ wd, const QcTrig* __restrict__ trig, int absorb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= T * n) return;
   const int t = i / n, w = i % n;
   const int64_t p = p0 + t;
   float* o = wd + (size_t)i * 8;
-  const float a = ajets[(int64_t)w * B + p];
+  // absorb: gate w is RX(theta_w) on wire w right after the embedding RX(a_w): one rotation by a_w + theta_w
+  const float a = ajets[(int64_t)w * B + p] + (absorb ? trig[w].th : 0.f);
   float s, c;
   sincosf(0.5f * a, &s, &c);
   o[0] = c;
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(256) k_hbm_init(const float* __restrict__ wd, 
     Cplx v;
     v.re = ph == 0 ? m : (ph == 2 ? -m : 0.f);
     v.im = ph == 1 ? -m : (ph == 3 ? m : 0.f);
-    chi[((size_t)c * T + t) * N + k] = v;
+    if (chi != nullptr) chi[((size_t)c * T + t) * N + k] = v;   // (nullptr: only the series is wanted)
     if constexpr (KEEP_SERIES) ser[((size_t)c * T + t) * N + k] = m;
   }
 }
@@ -374,6 +375,14 @@ __global__ void k_hbm_zero(float* __restrict__ p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
 }
+// folded RX layer: d L / d theta_w = sum over the tile's points of d L / d a_w (value-channel row w of abar)
+__global__ void __launch_bounds__(64) k_hbm_absorb_grad(const float* __restrict__ abar, int64_t B, int64_t p0, int T,
+                                                        const QcGate* __restrict__ prog, float* __restrict__ acc) {
+  const int w = blockIdx.x;
+  float v = (int)threadIdx.x < T ? abar[(int64_t)w * B + p0 + threadIdx.x] : 0.f;
+  v = qc_wave_sum_to_lane63(v);
+  if (threadIdx.x == 63) acc[prog[w].slot] += v;
+}
 __global__ void k_hbm_store_row(const float* __restrict__ acc, int n_params, float* __restrict__ row) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_params) row[i] = acc[i];
@@ -635,6 +644,11 @@ constexpr int W_GROUPS = 16;
 
 inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
+inline bool no_absorb() {
+  static const bool f = [] { const char* e = getenv("QC_NO_ABSORB"); return e && e[0] == '1'; }();
+  return f;
+}
+
 inline bool use_simple() {
   static const bool f = [] { const char* e = getenv("QC_HBM_SIMPLE"); return e && e[0] == '1'; }();
   return f;   // test hook: one pass per gate (the staged path's cross-check)
@@ -662,7 +676,9 @@ QcHbmPlan* qc_hbm_plan_create(const qc_program* pg) {
   QcHbmPlanPriv* P = new QcHbmPlanPriv();
   struct Tmp { int kind; std::vector<int> gates; std::vector<int> extra; };
   std::vector<Tmp> tmp;
-  for (int g = 0; g < pg->n_gates; ++g) {
+  const int absorb = (pg->lead_rx && !pg->amplitude && !no_absorb()) ? 1 : 0;
+  P->pub.absorb = absorb;
+  for (int g = absorb ? n : 0; g < pg->n_gates; ++g) {
     const QcGate& gt = pg->h_gates[g];
     if (is_diag_op(gt.op)) {
       if (tmp.empty() || tmp.back().kind != 1) tmp.push_back({1, {}, {}});
@@ -810,6 +826,16 @@ size_t qc_hbm_workspace_bytes(const qc_program* pg, int nch, bool backward) {
   return b;
 }
 
+// one tile's [chi | lam] slot of the kept-state store (6 channels x 64 points x 2^n amplitudes, twice), in complex64
+size_t qc_hbm_keep_slot_elems(const qc_program* pg) { return (size_t)2 * 6 * 64 * ((size_t)1 << pg->n_qubits); }
+// bytes of the store for B residual points, or 0 when it would exceed the budget (QC_HBM_KEEP_GB, default 96 GiB)
+size_t qc_hbm_keep_bytes(const qc_program* pg, int64_t B) {
+  static const double cap_gb = [] { const char* e = getenv("QC_HBM_KEEP_GB"); return e ? atof(e) : 96.0; }();
+  if (B <= 0) return 0;
+  const double bytes = (double)qc_ceil_div(B, 64) * (double)qc_hbm_keep_slot_elems(pg) * sizeof(Cplx);
+  return bytes <= cap_gb * 1073741824.0 ? (size_t)bytes : 0;
+}
+
 static Ws carve(const qc_program* pg, int nch, bool backward, void* ws) {
   const size_t N = (size_t)1 << pg->n_qubits, T = 64;
   const QcHbmPlan* plan = (const QcHbmPlan*)pg->hbm_plan;
@@ -904,31 +930,40 @@ static void staged_backward(const qc_program* pg, const QcTrig* trig, const floa
 template <int NCH>
 static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* umat,
                    const float* ajets, float* qjets, const float* qbar, float* abar, float* part, int64_t part_stride,
-                   int64_t row0, int64_t B, void* ws, size_t ws_bytes, hipStream_t st) {
+                   int64_t row0, int64_t B, void* ws, size_t ws_bytes, hipStream_t st, Cplx* store = nullptr) {
+  // store != nullptr (fused step, enough HBM): every 64-point tile owns a [chi | lam] slot there.  The forward
+  // call evolves each tile in its slot and leaves the final states; the backward call finds them and skips
+  // the forward recompute (only the embedding series is rebuilt).  288 GB of HBM holds ~700 such tiles at n = 16.
   const bool backward = qbar != nullptr;
   if (!ws || ws_bytes < qc_hbm_workspace_bytes(pg, NCH, backward)) return QC_ERR_ARG;
   const int n = pg->n_qubits;
   const int64_t N = (int64_t)1 << n;
+  const bool kept = backward && store != nullptr;
   Ws w = carve(pg, NCH, backward, ws);
   const bool staged = pg->hbm_plan != nullptr && !use_simple();
+  const int absorb = (staged && ((const QcHbmPlan*)pg->hbm_plan)->absorb) ? 1 : 0;   // the per-gate path runs every gate
   if (staged) build_tables(pg, trig_dev, w, st);
   for (int64_t p0 = 0; p0 < B; p0 += 64) {
     const int T = (int)((B - p0) < 64 ? (B - p0) : 64);
     const int TA = T;                                   // layout stride = points of this tile
+    if (store != nullptr) w.chi = store + (size_t)(p0 / 64) * qc_hbm_keep_slot_elems(pg);
     if (backward) w.lam = w.chi + (size_t)NCH * T * N;  // lam directly behind chi: GRAD pairs v with v + nvec
     const int64_t amps = (int64_t)TA * N;
     if (pg->amplitude) {
-      hipLaunchKernelGGL((k_hbm_init_amp<NCH>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, ajets, B, p0, TA, n, w.chi);
+      if (!kept)
+        hipLaunchKernelGGL((k_hbm_init_amp<NCH>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, ajets, B, p0, TA, n, w.chi);
     } else {
-      hipLaunchKernelGGL((k_hbm_wiredata<NCH>), dim3(qc_ceil_div((int64_t)T * n, 256)), dim3(256), 0, st, ajets, B, p0, T, n, w.wd);
+      hipLaunchKernelGGL((k_hbm_wiredata<NCH>), dim3(qc_ceil_div((int64_t)T * n, 256)), dim3(256), 0, st, ajets, B, p0, T, n, w.wd,
+                         trig_dev, absorb);
       if (backward)
-        hipLaunchKernelGGL((k_hbm_init<NCH, true>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n, w.chi, w.ser);
+        hipLaunchKernelGGL((k_hbm_init<NCH, true>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n,
+                           kept ? (Cplx*)nullptr : w.chi, w.ser);
       else
         hipLaunchKernelGGL((k_hbm_init<NCH, false>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.wd, TA, n, w.chi, w.ser);
     }
     const int64_t S = (int64_t)NCH * TA;
-    if (staged) staged_forward(pg, trig_dev, umat, w, S, st);
-    for (int g = 0; g < pg->n_gates && !staged; ++g) {
+    if (staged && !kept) staged_forward(pg, trig_dev, umat, w, S, st);
+    for (int g = 0; g < pg->n_gates && !staged && !kept; ++g) {
       const QcGate gt = pg->h_gates[g];
       if (gt.op == QC_U4)
         hipLaunchKernelGGL(k_hbm_u4, dim3(qc_ceil_div(S * (N / 4), 256)), dim3(256), 0, st, w.chi, S, n, gt.ba, gt.bb,
@@ -962,11 +997,25 @@ static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* um
     if (pg->amplitude)
       hipLaunchKernelGGL((k_hbm_abar_amp<NCH>), dim3(qc_ceil_div((int64_t)NCH * T * n, 256)), dim3(256), 0, st, w.lam, TA, n, B, p0, abar);
     else
+    {
       hipLaunchKernelGGL((k_hbm_abar<NCH>), dim3(n * T), dim3(256), 0, st, w.lam, w.ser, TA, n, B, p0, abar);
+      if (absorb) hipLaunchKernelGGL(k_hbm_absorb_grad, dim3(n), dim3(64), 0, st, abar, B, p0, T, pg->d_gates, w.acc);
+    }
     hipLaunchKernelGGL(k_hbm_store_row, dim3(qc_ceil_div(pg->n_params > 0 ? pg->n_params : 1, 256)), dim3(256), 0, st,
                        w.acc, pg->n_params, part + (row0 + p0 / 64) * part_stride);
   }
   return QC_OK;
+}
+
+// fused step with the final states kept per tile: `store` = ceil(B/64) slots of qc_hbm_keep_slot_elems() complex64
+int qc_hbm_forward_keep(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
+                        int64_t B, void* ws, size_t ws_bytes, void* store, hipStream_t st) {
+  return hbm_run<6>(pg, trig, umat, ajets, qjets, nullptr, nullptr, nullptr, 0, 0, B, ws, ws_bytes, st, (Cplx*)store);
+}
+int qc_hbm_backward_kept(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
+                         const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
+                         void* ws, size_t ws_bytes, void* store, hipStream_t st) {
+  return hbm_run<6>(pg, trig, umat, ajets, nullptr, qbar, abar, part, part_stride, row0, B, ws, ws_bytes, st, (Cplx*)store);
 }
 
 int qc_hbm_forward(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,

@@ -49,6 +49,7 @@ struct QcHbmPlan {
   QcDiagGate* h_dgates;
   QcDiagGate* d_dgates;
   int max_param_lgates;   // largest number of parametric gates in one L stage
+  int absorb;             // 1: gates 0..n-1 (leading RX layer) are folded into the embedding angles and not staged
 };
 
 QcHbmPlan* qc_hbm_plan_create(const qc_program* pg);

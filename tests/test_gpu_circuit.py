@@ -91,6 +91,7 @@ def test_expval_vjp_matches_oracle_autograd(ans, n, L, seed, B, gpu_device):
     ("cascade", 4, 1, 1, 70), ("layered", 4, 1, 1, 9), ("cross_mesh", 4, 1, 1, 6), ("cascade", 3, 1, None, 8),
     ("cascade", 2, 1, None, 5), ("alternate", 5, 1, 1, 5),
     ("cascade", 6, 1, 1, 3), ("layered", 7, 1, 1, 2), ("layered", 8, 1, 1, 1), ("sim_circ_15", 6, 1, 1, 2),
+    ("cascade", 7, 1, 1, 1),   # no generated static program: the run-time interpreter of the wave family
     ("cascade", 9, 1, 1, 1),   # (8-qubit x2 layers and n = 10 are covered by the training fixture / the value tests:
 ])                             #  the float64 oracle's jets cost ~1 min per case there)
 def test_jets_forward_and_vjp_match_oracle(ans, n, L, seed, B, gpu_device):
