@@ -17,6 +17,8 @@
 #include "qc_internal.h"
 #include "qc_hbm_plan.h"
 
+#include <type_traits>
+
 #include <stdlib.h>
 #include <string.h>
 
@@ -482,34 +484,69 @@ __global__ void __launch_bounds__(256) k_hbm_stage(Cplx* __restrict__ st, int64_
     }
     const QcTrig tr = trig[g.gi];
     const float c = tr.c, s = ADJ ? -tr.s : tr.s;
-    float a0r, a0i, b0r, b0i, a1r, a1i, b1r, b1i;
-    coef_of(g.op, c, s, false, a0r, a0i, b0r, b0i);
-    coef_of(g.op, c, s, true, a1r, a1i, b1r, b1i);
     float grad = 0.f;
-    for (int p = threadIdx.x; p < (TS >> 1); p += 256) {
-      const int i0 = ((p >> g.jt) << (g.jt + 1)) | (p & ((1 << g.jt) - 1));
-      const int i1 = i0 | (1 << g.jt);
-      if (g.jc >= 0 && !((i0 >> g.jc) & 1)) continue;
-      const Cplx x0 = t0[i0], x1 = t0[i1];
-      if constexpr (GRAD) {
-        const Cplx q0 = t1[i0], q1 = t1[i1];
-        switch (g.op) {
-          case QC_RX: case QC_CRX:
-            grad += (q0.re * x1.im - q0.im * x1.re) + (q1.re * x0.im - q1.im * x0.re);
-            break;
-          case QC_RY:
-            grad += -(q0.re * x1.re + q0.im * x1.im) + (q1.re * x0.re + q1.im * x0.im);
-            break;
-          case QC_RZ: case QC_CRZ:
-            grad += (q0.re * x0.im - q0.im * x0.re) - (q1.re * x1.im - q1.im * x1.re);
-            break;
-          default: break;
+    // op-specialised pair update (wave-uniform switch outside the pair loop): 4 mul + 4 fma per pair and
+    // vector for the rotations instead of the generic 2x2 complex form (16), gradient term inline.
+    // (Batching several gates per LDS round trip - a thread owning the 2^m amplitudes spanned by m target bits -
+    // was measured slower: adjacent gates target adjacent low bits, so lanes stride 2^m amplitudes and collide
+    // in the LDS banks; it needs a padded/swizzled tile, for which the 64 KiB of the sweep's two tiles leave no room.)
+    auto pairs = [&](auto OPC) {
+      constexpr int OP = decltype(OPC)::value;
+      constexpr bool ctl = (OP == QC_CNOT || OP == QC_CRX || OP == QC_CRZ);
+      auto upd = [&](Cplx& a, Cplx& b) {   // (a, b) = amplitudes with target bit 0 / 1
+        const Cplx x0 = a, x1 = b;
+        if constexpr (OP == QC_RX || OP == QC_CRX) {
+          a = {fmaf(s, x1.im, c * x0.re), fmaf(-s, x1.re, c * x0.im)};
+          b = {fmaf(s, x0.im, c * x1.re), fmaf(-s, x0.re, c * x1.im)};
+        } else if constexpr (OP == QC_RY) {
+          a = {fmaf(-s, x1.re, c * x0.re), fmaf(-s, x1.im, c * x0.im)};
+          b = {fmaf(s, x0.re, c * x1.re), fmaf(s, x0.im, c * x1.im)};
+        } else if constexpr (OP == QC_RZ || OP == QC_CRZ) {
+          a = {fmaf(s, x0.im, c * x0.re), fmaf(-s, x0.re, c * x0.im)};
+          b = {fmaf(-s, x1.im, c * x1.re), fmaf(s, x1.re, c * x1.im)};
+        } else if constexpr (OP == QC_H) {
+          const float h = 0.70710678118654752440f;
+          a = {h * (x0.re + x1.re), h * (x0.im + x1.im)};
+          b = {h * (x0.re - x1.re), h * (x0.im - x1.im)};
+        } else {   // CNOT
+          a = x1;
+          b = x0;
         }
-        t1[i0] = {a0r * q0.re - a0i * q0.im + b0r * q1.re - b0i * q1.im, a0r * q0.im + a0i * q0.re + b0r * q1.im + b0i * q1.re};
-        t1[i1] = {a1r * q1.re - a1i * q1.im + b1r * q0.re - b1i * q0.im, a1r * q1.im + a1i * q1.re + b1r * q0.im + b1i * q0.re};
+      };
+#pragma unroll 2
+      for (int p = threadIdx.x; p < (TS >> 1); p += 256) {
+        const int i0 = ((p >> g.jt) << (g.jt + 1)) | (p & ((1 << g.jt) - 1));
+        const int i1 = i0 | (1 << g.jt);
+        if constexpr (ctl) {
+          if (!((i0 >> g.jc) & 1)) continue;
+        }
+        Cplx x0 = t0[i0], x1 = t0[i1];
+        if constexpr (GRAD) {
+          Cplx q0 = t1[i0], q1 = t1[i1];
+          if constexpr (OP == QC_RX || OP == QC_CRX)
+            grad += (q0.re * x1.im - q0.im * x1.re) + (q1.re * x0.im - q1.im * x0.re);
+          else if constexpr (OP == QC_RY)
+            grad += -(q0.re * x1.re + q0.im * x1.im) + (q1.re * x0.re + q1.im * x0.im);
+          else if constexpr (OP == QC_RZ || OP == QC_CRZ)
+            grad += (q0.re * x0.im - q0.im * x0.re) - (q1.re * x1.im - q1.im * x1.re);
+          upd(q0, q1);
+          t1[i0] = q0;
+          t1[i1] = q1;
+        }
+        upd(x0, x1);
+        t0[i0] = x0;
+        t0[i1] = x1;
       }
-      t0[i0] = {a0r * x0.re - a0i * x0.im + b0r * x1.re - b0i * x1.im, a0r * x0.im + a0i * x0.re + b0r * x1.im + b0i * x1.re};
-      t0[i1] = {a1r * x1.re - a1i * x1.im + b1r * x0.re - b1i * x0.im, a1r * x1.im + a1i * x1.re + b1r * x0.im + b1i * x0.re};
+    };
+    switch (g.op) {
+      case QC_RX: pairs(std::integral_constant<int, QC_RX>{}); break;
+      case QC_RY: pairs(std::integral_constant<int, QC_RY>{}); break;
+      case QC_RZ: pairs(std::integral_constant<int, QC_RZ>{}); break;
+      case QC_H: pairs(std::integral_constant<int, QC_H>{}); break;
+      case QC_CNOT: pairs(std::integral_constant<int, QC_CNOT>{}); break;
+      case QC_CRX: pairs(std::integral_constant<int, QC_CRX>{}); break;
+      case QC_CRZ: pairs(std::integral_constant<int, QC_CRZ>{}); break;
+      default: break;
     }
     if constexpr (GRAD) {
       if (g.slot >= 0) {
