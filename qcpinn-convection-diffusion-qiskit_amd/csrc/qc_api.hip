@@ -415,7 +415,37 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
                                           d->sample_off_ic, d->B_val - d->n_ic, d->sample_off_bc,
                                           d->sample_bc_face_points, d->sample_seed, d->sample_step, st))) return rc;
   }
-  if (phases & QC_PHASE_GRADS) {
+  // register family, angle encoding, both pipelines present, final-state store available: every stage is ONE launch
+  // over the residual tiles and the value tiles together (no side stream, 9 launches per step); QC_NO_MERGE=1 keeps
+  // the two-stream form below
+  static const bool no_merge = [] { const char* e = getenv("QC_NO_MERGE"); return e && e[0] == '1'; }();
+  const bool merged = (phases & QC_PHASE_GRADS) && !no_merge && use_reg(n) && !amp && d->B_res > 0 && d->B_val > 0 && cws &&
+                      cws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res);
+  if (merged) {
+    if (!d->X_res_dev || !d->ajets_res_dev || !d->qjets_res_dev || !d->qbar_res_dev || !d->abar_res_dev || !d->X_val_dev ||
+        !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
+      return QC_ERR_ARG;
+    QcPde pde;
+    memcpy(&pde, &d->pde, sizeof(pde));
+    const float* prm = d->params_dev;
+    float* chi_store = (float*)cws;
+    if ((rc = qc_mlp_pre_fwd_both((const float*)d->X_res_dev, (const float*)d->X_val_dev, prm, L, d->ajets_res_dev,
+                                  d->ajets_val_dev, d->B_res, d->B_val, st))) return rc;
+    if ((rc = qc_reg_circ_fwd_both(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, chi_store,
+                                   d->ajets_val_dev, d->qjets_val_dev, d->B_val, st))) return rc;
+    // abar_* are written only by the adjoint sweep below: their heads serve as per-point cotangent scratch here
+    if ((rc = qc_mlp_post_both(prm, L, pde, (const float*)d->X_res_dev, d->qjets_res_dev, d->abar_res_dev,
+                               d->abar_res_dev + d->B_res, d->qbar_res_dev, 0, d->B_res, (const float*)d->X_val_dev,
+                               d->qjets_val_dev, d->abar_val_dev, d->qbar_val_dev, rows_res, d->B_val, d->part_dev,
+                               d->part_stride, st))) return rc;
+    if ((rc = qc_reg_circ_bwd_both(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev, 0, d->B_res,
+                                   chi_store, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev, rows_res, d->B_val,
+                                   d->part_dev + L.oTh, d->part_stride, st))) return rc;
+    if ((rc = qc_mlp_pre_bwd_both((const float*)d->X_res_dev, (const float*)d->X_val_dev, prm, L, d->abar_res_dev,
+                                  d->abar_val_dev, d->part_dev, d->part_stride, 0, rows_res, d->B_res, d->B_val, st))) return rc;
+    if ((rc = after_launch())) return rc;
+  }
+  if ((phases & QC_PHASE_GRADS) && !merged) {
     // the two pipelines are independent until the row reduction: fork the value pipeline onto a side
     // stream (not for n >= 9, where both would share the HBM statevector workspace)
     QcSide* side = (d->B_res > 0 && d->B_val > 0 && !use_hbm(n)) ? side_stream() : nullptr;
@@ -490,6 +520,8 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);
       if (e != hipSuccess) return hip_fail(e);
     }
+  }
+  if (phases & QC_PHASE_GRADS) {
     // the step owns its partial-row matrix, so the reduction folds it in place (two levels, fixed order);
     // with the update phase in the same call the second level rides in the optimiser launch
     const int RS = qc_opt_fold_rows(d->part_dev, rows, d->part_stride, L.NP + 3, st);

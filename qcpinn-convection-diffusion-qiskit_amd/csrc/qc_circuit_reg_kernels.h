@@ -231,13 +231,13 @@ __device__ __forceinline__ const float* qc_launder(const float* p) {
 }
 
 // ================================================================== value channel only
-template <class PG>
-__global__ void __launch_bounds__(256) k_value_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+template <class PG, int WPB>
+__device__ __forceinline__ void k_value_fwd_body(const int64_t bid, const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                    const float* __restrict__ umat, int n_gates,
                                                    const float* __restrict__ angles, float* __restrict__ expval,
                                                    int64_t B, int amp) {
   constexpr int N = PG::N;
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t p = (int64_t)bid * (64 * WPB) + threadIdx.x;
   const int64_t pc = p < B ? p : B - 1;
   SV<N> v[1];
   build_channel<N>(v[0], 0, angles, B, pc, amp & 1, trig, amp >> 1);
@@ -253,18 +253,26 @@ __global__ void __launch_bounds__(256) k_value_fwd(const QcGate* __restrict__ pr
 }
 
 template <class PG>
-__global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+__global__ void __launch_bounds__(256) k_value_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                   const float* __restrict__ umat, int n_gates,
+                                                   const float* __restrict__ angles, float* __restrict__ expval,
+                                                   int64_t B, int amp) {
+  k_value_fwd_body<PG, 4>(blockIdx.x, prog, trig, umat, n_gates, angles, expval, B, amp);
+}
+
+template <class PG, int WPB>
+__device__ __forceinline__ void k_value_bwd_body(const int64_t bid, const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                    const float* __restrict__ umat, int n_gates, int n_params,
                                                    const float* __restrict__ angles, const float* __restrict__ cot,
                                                    float* __restrict__ d_angles, float* __restrict__ part,
                                                    int64_t part_stride, int64_t row0, int64_t B, int amp) {
   constexpr int N = PG::N;
-  extern __shared__ float smem[];  // [4 waves][n_params]
+  extern __shared__ float smem[];  // [WPB waves][n_params]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < 4 * n_params; i += 256) smem[i] = 0.f;
+  for (int i = threadIdx.x; i < WPB * n_params; i += 64 * WPB) smem[i] = 0.f;
   __syncthreads();
 
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t p = (int64_t)bid * (64 * WPB) + threadIdx.x;
   const bool live = p < B;
   const int64_t pc = live ? p : B - 1;
   SV<N> cl[2];  // [0] = chi, [1] = lambda
@@ -308,9 +316,18 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
   }
   __syncthreads();
   // one partial row per wave = per 64-point tile (same tiling as the MLP kernels)
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t tile = (int64_t)bid * WPB + wave;
   if (tile * 64 < B)
     for (int i = lane; i < n_params; i += 64) part[(row0 + tile) * part_stride + i] = smem[wave * n_params + i];
+}
+
+template <class PG>
+__global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                   const float* __restrict__ umat, int n_gates, int n_params,
+                                                   const float* __restrict__ angles, const float* __restrict__ cot,
+                                                   float* __restrict__ d_angles, float* __restrict__ part,
+                                                   int64_t part_stride, int64_t row0, int64_t B, int amp) {
+  k_value_bwd_body<PG, 4>(blockIdx.x, prog, trig, umat, n_gates, n_params, angles, cot, d_angles, part, part_stride, row0, B, amp);
 }
 
 // Final-state store handed from k_jets_fwd to k_jets_bwd: tile-major, so the 6 x A2 x 64 floats one
@@ -322,7 +339,7 @@ __device__ __forceinline__ int64_t qc_chi_index(int ch, int k2, int64_t p) {
 
 // ================================================================== six derivative channels
 template <class PG>
-__global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+__device__ __forceinline__ void k_jets_fwd_body(const int64_t bid, const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates,
                                                   const float* __restrict__ ajets, float* __restrict__ qjets,
                                                   int64_t B, float* __restrict__ chi_store, int amp) {
@@ -332,7 +349,7 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
   __shared__ float s_sq[2 * N * 64];         // 2<chi_k|Z_w|chi_k> for k = x, y
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave index = channel (scalar)
-  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t p = (int64_t)bid * 64 + lane;
   const int64_t pc = p < B ? p : B - 1;
 
   SV<N> v[1];
@@ -381,13 +398,21 @@ __global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ pro
   }
 }
 
+template <class PG>
+__global__ void __launch_bounds__(384) k_jets_fwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                  const float* __restrict__ umat, int n_gates,
+                                                  const float* __restrict__ ajets, float* __restrict__ qjets,
+                                                  int64_t B, float* __restrict__ chi_store, int amp) {
+  k_jets_fwd_body<PG>(blockIdx.x, prog, trig, umat, n_gates, ajets, qjets, B, chi_store, amp);
+}
+
 #ifndef QC_JB_WAVES
 #define QC_JB_WAVES 3
 #endif
 // LOAD: the final states come from chi_store (written by k_jets_fwd in the same step) instead of being
 // recomputed from the angle jets: 12 instead of 18 circuit-equivalents per point.
 template <class PG, bool LOAD>
-__global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+__device__ __forceinline__ void k_jets_bwd_body(const int64_t bid, const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
                                                   const float* __restrict__ umat, int n_gates, int n_params,
                                                   const float* __restrict__ ajets, const float* __restrict__ qbar,
                                                   float* __restrict__ abar, float* __restrict__ part,
@@ -404,7 +429,7 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
   for (int i = threadIdx.x; i < 6 * n_params; i += 384) s_acc[i] = 0.f;
   if constexpr (LOAD) __syncthreads();   // (the !LOAD path has its barrier after the state exchange)
 
-  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t p = (int64_t)bid * 64 + lane;
   const bool live = p < B;
   const int64_t pc = live ? p : B - 1;
 
@@ -560,8 +585,44 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < 6; ++wv) s += s_acc[wv * n_params + i];
-    part[(row0 + blockIdx.x) * part_stride + i] = s;
+    part[(row0 + bid) * part_stride + i] = s;
   }
+}
+
+template <class PG, bool LOAD>
+__global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                  const float* __restrict__ umat, int n_gates, int n_params,
+                                                  const float* __restrict__ ajets, const float* __restrict__ qbar,
+                                                  float* __restrict__ abar, float* __restrict__ part,
+                                                  int64_t part_stride, int64_t row0, int64_t B,
+                                                  const float* __restrict__ chi_store, int amp) {
+  k_jets_bwd_body<PG, LOAD>(blockIdx.x, prog, trig, umat, n_gates, n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, amp);
+}
+
+// ---- residual + value tiles in one launch (see qc_mlp.hip): blocks [0, n_val) run the value-channel kernel on
+// 6 x 64 boundary / initial points, the rest the six-channel kernel on a 64-point residual tile
+template <class PG>
+__global__ void __launch_bounds__(384) k_circ_fwd_both(const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                       const float* __restrict__ umat, int n_gates,
+                                                       const float* __restrict__ ajets, float* __restrict__ qjets, int64_t Br,
+                                                       float* __restrict__ chi_store, const float* __restrict__ angles,
+                                                       float* __restrict__ expval, int64_t Bv, int amp, int n_val) {
+  if ((int)blockIdx.x >= n_val) k_jets_fwd_body<PG>(blockIdx.x - n_val, prog, trig, umat, n_gates, ajets, qjets, Br, chi_store, amp);
+  else k_value_fwd_body<PG, 6>(blockIdx.x, prog, trig, umat, n_gates, angles, expval, Bv, amp);
+}
+
+template <class PG>
+__global__ void __launch_bounds__(384, QC_JB_WAVES) k_circ_bwd_both(
+    const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig, const float* __restrict__ umat, int n_gates, int n_params,
+    const float* __restrict__ ajets, const float* __restrict__ qbar, float* __restrict__ abar, int64_t row0_r, int64_t Br,
+    const float* __restrict__ chi_store, const float* __restrict__ angles, const float* __restrict__ cot,
+    float* __restrict__ d_angles, int64_t row0_v, int64_t Bv, float* __restrict__ part, int64_t part_stride, int amp, int n_val) {
+  if ((int)blockIdx.x >= n_val)
+    k_jets_bwd_body<PG, true>(blockIdx.x - n_val, prog, trig, umat, n_gates, n_params, ajets, qbar, abar, part, part_stride, row0_r, Br,
+                              chi_store, amp);
+  else
+    k_value_bwd_body<PG, 6>(blockIdx.x, prog, trig, umat, n_gates, n_params, angles, cot, d_angles, part, part_stride,
+                            row0_v, Bv, amp);
 }
 
 }  // namespace
@@ -581,6 +642,11 @@ struct QcRegLaunchers {
   int (*jets_fwd)(const qc_program*, const QcTrig*, const float*, const float*, float*, int64_t, float*, hipStream_t);
   int (*jets_bwd)(const qc_program*, const QcTrig*, const float*, const float*, const float*, float*, float*,
                   int64_t, int64_t, int64_t, const float*, hipStream_t);
+  // residual (six channels, chi_store required) + value tiles in one launch
+  int (*circ_fwd_both)(const qc_program*, const QcTrig*, const float*, const float*, float*, int64_t, float*, const float*,
+                       float*, int64_t, hipStream_t);
+  int (*circ_bwd_both)(const qc_program*, const QcTrig*, const float*, const float*, const float*, float*, int64_t, int64_t,
+                       const float*, const float*, const float*, float*, int64_t, int64_t, float*, int64_t, hipStream_t);
 };
 
 template <class PG>
@@ -627,5 +693,25 @@ struct RegLaunch {
                          pg->n_gates, pg->n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, qc_embed_flags(pg));
     return QC_OK;
   }
-  static constexpr QcRegLaunchers table() { return {&value_fwd, &value_bwd, &jets_fwd, &jets_bwd}; }
+  static int circ_fwd_both(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
+                           int64_t Br, float* chi_store, const float* angles, float* expval, int64_t Bv, hipStream_t st) {
+    const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 384);
+    hipLaunchKernelGGL(k_circ_fwd_both<PG>, dim3(nr + nv), dim3(384), 0, st, pg->d_gates, trig, umat, pg->n_gates, ajets,
+                       qjets, Br, chi_store, angles, expval, Bv, qc_embed_flags(pg), nv);
+    return QC_OK;
+  }
+  static int circ_bwd_both(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
+                           const float* qbar, float* abar, int64_t row0_r, int64_t Br, const float* chi_store,
+                           const float* angles, const float* cot, float* d_angles, int64_t row0_v, int64_t Bv, float* part,
+                           int64_t part_stride, hipStream_t st) {
+    const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 384);
+    const size_t sh = ((size_t)6 * 3 * PG::N * 64 + (size_t)6 * pg->n_params) * sizeof(float);   // >= the value blocks' 6 rows
+    hipLaunchKernelGGL(k_circ_bwd_both<PG>, dim3(nr + nv), dim3(384), sh, st, pg->d_gates, trig, umat, pg->n_gates,
+                       pg->n_params, ajets, qbar, abar, row0_r, Br, chi_store, angles, cot, d_angles, row0_v, Bv, part,
+                       part_stride, qc_embed_flags(pg), nv);
+    return QC_OK;
+  }
+  static constexpr QcRegLaunchers table() {
+    return {&value_fwd, &value_bwd, &jets_fwd, &jets_bwd, &circ_fwd_both, &circ_bwd_both};
+  }
 };

@@ -67,6 +67,20 @@ int qc_reg_jets_fwd(const qc_program*, const QcTrig*, const float* umat, const f
 int qc_reg_jets_bwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, const float* qbar,
                     float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, const float* chi_store,
                     hipStream_t);
+int qc_reg_circ_fwd_both(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
+                         int64_t Br, float* chi_store, const float* angles, float* expval, int64_t Bv, hipStream_t st);
+int qc_reg_circ_bwd_both(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
+                         const float* qbar, float* abar, int64_t row0_r, int64_t Br, const float* chi_store,
+                         const float* angles, const float* cot, float* d_angles, int64_t row0_v, int64_t Bv, float* part,
+                         int64_t part_stride, hipStream_t st);
+int qc_mlp_pre_fwd_both(const float* Xr, const float* Xv, const float* prm, QcLayout L, float* ajr, float* ajv,
+                        int64_t Br, int64_t Bv, hipStream_t st);
+int qc_mlp_pre_bwd_both(const float* Xr, const float* Xv, const float* prm, QcLayout L, const float* abr, const float* abv,
+                        float* part, int64_t part_stride, int64_t row0_r, int64_t row0_v, int64_t Br, int64_t Bv,
+                        hipStream_t st);
+int qc_mlp_post_both(const float* prm, QcLayout L, QcPde pde, const float* Xr, const float* qjr, float* ubr, float* rbr,
+                     float* qbr, int64_t row0_r, int64_t Br, const float* Xv, const float* qjv, float* ubv, float* qbv,
+                     int64_t row0_v, int64_t Bv, float* part, int64_t part_stride, hipStream_t st);
 size_t qc_reg_chi_store_bytes(const qc_program* pg, int64_t B);
 int qc_wave_match_static(const qc_program*);
 int qc_wave_value_fwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, float* expval,

@@ -56,12 +56,12 @@ __device__ __forceinline__ float analytic_u_diffusion(float t, float x, float y,
 constexpr int QC_MS = 4;
 
 template <int N, int NCH>
-__global__ void __launch_bounds__(256) k_pre_fwd(const float* __restrict__ X, const float* __restrict__ prm,
+__device__ __forceinline__ void k_pre_fwd_body(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm,
                                                  QcLayout L, float* __restrict__ ajets, int64_t B) {
   __shared__ float s_part[QC_MS][NCH * N][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t p = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t p = (int64_t)bid * 64 + lane;
   const int64_t pc = p < B ? p : B - 1;
   const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
   float acc[NCH][N];
@@ -109,18 +109,24 @@ __global__ void __launch_bounds__(256) k_pre_fwd(const float* __restrict__ X, co
   }
 }
 
+template <int N, int NCH>
+__global__ void __launch_bounds__(256) k_pre_fwd(const float* __restrict__ X, const float* __restrict__ prm,
+                                                 QcLayout L, float* __restrict__ ajets, int64_t B) {
+  k_pre_fwd_body<N, NCH>(blockIdx.x, X, prm, L, ajets, B);
+}
+
 // ================================================================== pre network, reverse pass
 // lane = hidden unit (each lane owns one row of W1 / column of W2, so weight gradients need no
 // cross-lane reduction).  The block's 64-point tile is staged in LDS and split over PS groups of HB
 // threads (16 points each, read as LDS broadcasts); the groups' accumulators meet in LDS.
 template <int N, int NCH>
-__global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+__device__ __forceinline__ void k_pre_bwd_body(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
                           const float* __restrict__ abar, float* __restrict__ part, int64_t part_stride,
                           int64_t row0, int64_t B, int HB, int PS) {
   __shared__ float sX[3][64];
   __shared__ float sA[NCH * N][64];
   extern __shared__ float s_acc[];  // [PS][4 + N][HB]
-  const int64_t base = (int64_t)blockIdx.x * 64;
+  const int64_t base = (int64_t)bid * 64;
   const int cnt = (int)((B - base) < 64 ? (B - base) : 64);
   for (int i = threadIdx.x; i < 64 * 3; i += blockDim.x) {
     const int pp = i / 3, k = i % 3;
@@ -195,7 +201,7 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
     for (int i = 0; i < N; ++i) mine[(4 + i) * HB + m] = gW2[i];
   }
   __syncthreads();
-  float* row = part + (row0 + blockIdx.x) * part_stride;
+  float* row = part + (row0 + bid) * part_stride;
   if (grp == 0 && m < L.H) {
     float tot[4 + N];
 #pragma unroll
@@ -216,6 +222,13 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
     for (int pp = 0; pp < cnt; ++pp) sum += sA[threadIdx.x][pp];
     row[L.ob2 + threadIdx.x] = sum;
   }
+}
+
+template <int N, int NCH>
+__global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+                          const float* __restrict__ abar, float* __restrict__ part, int64_t part_stride,
+                          int64_t row0, int64_t B, int HB, int PS) {
+  k_pre_bwd_body<N, NCH>(blockIdx.x, X, prm, L, abar, part, part_stride, row0, B, HB, PS);
 }
 
 // ================================================================== post network + PDE + loss
@@ -262,7 +275,7 @@ __device__ __forceinline__ void expand_ub(float (&ub)[NCH], float ub0, float gsc
 }
 
 template <int N, int NCH, int MODE>
-__global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+__device__ __forceinline__ void k_post_body(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
                                               QcPde pde, const float* __restrict__ qjets,
                                               float* __restrict__ out_u, float* __restrict__ out_res,
                                               const float* __restrict__ in_ubar, const float* __restrict__ in_rbar,
@@ -272,7 +285,7 @@ __global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const
   __shared__ float s_buf[QC_MS][NCH * N][64];   // partial u jets first (NCH rows), partial qbar later
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t tile = blockIdx.x;
+  const int64_t tile = bid;
   const int64_t p = tile * 64 + lane;
   const bool live = p < B;
   const int64_t pc = live ? p : B - 1;
@@ -411,17 +424,27 @@ __global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const
   }
 }
 
+template <int N, int NCH, int MODE>
+__global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+                                              QcPde pde, const float* __restrict__ qjets,
+                                              float* __restrict__ out_u, float* __restrict__ out_res,
+                                              const float* __restrict__ in_ubar, const float* __restrict__ in_rbar,
+                                              float* __restrict__ qbar, float* __restrict__ part,
+                                              int64_t part_stride, int64_t row0, int64_t B) {
+  k_post_body<N, NCH, MODE>(blockIdx.x, X, prm, L, pde, qjets, out_u, out_res, in_ubar, in_rbar, qbar, part, part_stride, row0, B);
+}
+
 // Weight gradients of the post network: lane = hidden unit m (owns row m of W3, b3[m], W4[m]); the
 // block walks its 64-point tile, reading the tile's <Z> jets and per-point cotangents from LDS as
 // broadcasts.  No cross-lane reduction; one partial row per tile.
 template <int N, int NCH>
-__global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, const float* __restrict__ qjets,
+__device__ __forceinline__ void k_post_wg_body(const int64_t bid, const float* __restrict__ prm, QcLayout L, QcPde pde, const float* __restrict__ qjets,
                           const float* __restrict__ ubar, const float* __restrict__ rbar,
                           float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B, int HB, int PS) {
   __shared__ float sQ[NCH * N][64];
   __shared__ float sU[2][64];
   extern __shared__ float s_acc[];  // [PS][N + 2][HB]
-  const int64_t base = (int64_t)blockIdx.x * 64;
+  const int64_t base = (int64_t)bid * 64;
   const int cnt = (int)((B - base) < 64 ? (B - base) : 64);
   for (int i = threadIdx.x; i < NCH * N * 64; i += blockDim.x) {
     const int f = i >> 6, pp = i & 63;
@@ -477,7 +500,7 @@ __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, 
     mine[(N + 1) * HB + m] = gW4;
   }
   __syncthreads();
-  float* row = part + (row0 + blockIdx.x) * part_stride;
+  float* row = part + (row0 + bid) * part_stride;
   if (grp == 0 && m < L.H) {
     float tot[N + 2];
 #pragma unroll
@@ -496,6 +519,65 @@ __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, 
     for (int pp = 0; pp < cnt; ++pp) sum += sU[0][pp];
     row[L.ob4] = sum;
   }
+}
+
+template <int N, int NCH>
+__global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, const float* __restrict__ qjets,
+                          const float* __restrict__ ubar, const float* __restrict__ rbar,
+                          float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B, int HB, int PS) {
+  k_post_wg_body<N, NCH>(blockIdx.x, prm, L, pde, qjets, ubar, rbar, part, part_stride, row0, B, HB, PS);
+}
+
+// ================================================================== residual + value tiles in ONE launch
+// The fused step's two pipelines (65 536 residual points with 6 channels, 2 x 21 845 boundary / initial points with
+// the value channel) are independent until the row reduction.  Launching each stage once over the blocks of BOTH
+// (the lighter value tiles first, so the launch ends on full-occupancy residual tiles; block-uniform branch) removes the side stream, its two
+// cross-queue event waits (~7 us of idle queue each) and 6 of the step's 15 launches.
+template <int N>
+__global__ void __launch_bounds__(256) k_pre_fwd_both(const float* __restrict__ Xr, const float* __restrict__ Xv,
+                                                      const float* __restrict__ prm, QcLayout L, float* __restrict__ ajr,
+                                                      float* __restrict__ ajv, int64_t Br, int64_t Bv, int n_val) {
+  if ((int)blockIdx.x >= n_val) k_pre_fwd_body<N, 6>(blockIdx.x - n_val, Xr, prm, L, ajr, Br);
+  else k_pre_fwd_body<N, 1>(blockIdx.x, Xv, prm, L, ajv, Bv);
+}
+
+template <int N>
+__global__ void k_pre_bwd_both(const float* __restrict__ Xr, const float* __restrict__ Xv, const float* __restrict__ prm,
+                               QcLayout L, const float* __restrict__ abr, const float* __restrict__ abv,
+                               float* __restrict__ part, int64_t part_stride, int64_t row0_r, int64_t row0_v, int64_t Br,
+                               int64_t Bv, int HB, int PS, int n_val) {
+  if ((int)blockIdx.x >= n_val) k_pre_bwd_body<N, 6>(blockIdx.x - n_val, Xr, prm, L, abr, part, part_stride, row0_r, Br, HB, PS);
+  else k_pre_bwd_body<N, 1>(blockIdx.x, Xv, prm, L, abv, part, part_stride, row0_v, Bv, HB, PS);
+}
+
+struct QcPostSeg {   // one pipeline's arguments of the fused (mode 2) post kernels
+  const float* X;
+  const float* qjets;
+  float* ub;       // per-point cotangent of u (scratch, B floats)
+  float* rb;       // per-point cotangent of the residual (scratch, B floats; residual pipeline only)
+  float* qbar;
+  int64_t row0, B;
+};
+
+template <int N>
+__global__ void __launch_bounds__(256) k_post_both(const float* __restrict__ prm, QcLayout L, QcPde pde, QcPostSeg r,
+                                                   QcPostSeg v, float* __restrict__ part, int64_t part_stride,
+                                                   int n_val) {
+  if ((int)blockIdx.x >= n_val)
+    k_post_body<N, 6, 2>(blockIdx.x - n_val, r.X, prm, L, pde, r.qjets, r.ub, r.rb, nullptr, nullptr, r.qbar, part, part_stride,
+                         r.row0, r.B);
+  else
+    k_post_body<N, 1, 2>(blockIdx.x, v.X, prm, L, pde, v.qjets, v.ub, nullptr, nullptr, nullptr, v.qbar, part,
+                         part_stride, v.row0, v.B);
+}
+
+template <int N>
+__global__ void k_post_wg_both(const float* __restrict__ prm, QcLayout L, QcPde pde, QcPostSeg r, QcPostSeg v,
+                               float* __restrict__ part, int64_t part_stride, int HB, int PS, int n_val) {
+  if ((int)blockIdx.x >= n_val)
+    k_post_wg_body<N, 6>(blockIdx.x - n_val, prm, L, pde, r.qjets, r.ub, r.rb, part, part_stride, r.row0, r.B, HB, PS);
+  else
+    k_post_wg_body<N, 1>(blockIdx.x, prm, L, pde, v.qjets, v.ub, nullptr, part, part_stride, v.row0, v.B, HB, PS);
 }
 
 }  // namespace
@@ -588,5 +670,51 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
 #undef CALL
 #undef LAUNCH
 #undef LAUNCH_WG
+  return QC_OK;
+}
+
+// ------------------------------------------------------------------ merged residual + value launches (fused step)
+int qc_mlp_pre_fwd_both(const float* Xr, const float* Xv, const float* prm, QcLayout L, float* ajr, float* ajv,
+                        int64_t Br, int64_t Bv, hipStream_t st) {
+  const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 64);
+#define CALL(NN) \
+  hipLaunchKernelGGL((k_pre_fwd_both<NN>), dim3(nr + nv), dim3(256), 0, st, Xr, Xv, prm, L, ajr, ajv, Br, Bv, nv);
+  QC_MLP_DISPATCH(L.n, CALL)
+#undef CALL
+  return QC_OK;
+}
+
+int qc_mlp_pre_bwd_both(const float* Xr, const float* Xv, const float* prm, QcLayout L, const float* abr, const float* abv,
+                        float* part, int64_t part_stride, int64_t row0_r, int64_t row0_v, int64_t Br, int64_t Bv,
+                        hipStream_t st) {
+  if (L.H > 1024 || L.n > 64) return QC_ERR_UNSUPPORTED;
+  const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 64);
+  int HB, PS, threads;
+  hidden_geometry(L.H, &HB, &PS, &threads);
+  const size_t sh = (size_t)PS * (4 + L.n) * HB * sizeof(float);
+#define CALL(NN)                                                                                                   \
+  hipLaunchKernelGGL((k_pre_bwd_both<NN>), dim3(nr + nv), dim3(threads), sh, st, Xr, Xv, prm, L, abr, abv, part,    \
+                     part_stride, row0_r, row0_v, Br, Bv, HB, PS, nv);
+  QC_MLP_DISPATCH(L.n, CALL)
+#undef CALL
+  return QC_OK;
+}
+
+// mode-2 post stage of both pipelines: point kernel, then weight-gradient kernel
+int qc_mlp_post_both(const float* prm, QcLayout L, QcPde pde, const float* Xr, const float* qjr, float* ubr, float* rbr,
+                     float* qbr, int64_t row0_r, int64_t Br, const float* Xv, const float* qjv, float* ubv, float* qbv,
+                     int64_t row0_v, int64_t Bv, float* part, int64_t part_stride, hipStream_t st) {
+  if (L.H > 1024) return QC_ERR_UNSUPPORTED;
+  const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 64);
+  int HB, PS, threads;
+  hidden_geometry(L.H, &HB, &PS, &threads);
+  const size_t sh = (size_t)PS * (L.n + 2) * HB * sizeof(float);
+  const QcPostSeg r = {Xr, qjr, ubr, rbr, qbr, row0_r, Br}, v = {Xv, qjv, ubv, nullptr, qbv, row0_v, Bv};
+#define CALL(NN)                                                                                                      \
+  hipLaunchKernelGGL((k_post_both<NN>), dim3(nr + nv), dim3(256), 0, st, prm, L, pde, r, v, part, part_stride, nv);   \
+  hipLaunchKernelGGL((k_post_wg_both<NN>), dim3(nr + nv), dim3(threads), sh, st, prm, L, pde, r, v, part, part_stride, \
+                     HB, PS, nv);
+  QC_MLP_DISPATCH(L.n, CALL)
+#undef CALL
   return QC_OK;
 }
