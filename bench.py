@@ -44,16 +44,20 @@ class Log:
         return "/tmp"
 
 
-def algorithmic_flops_per_point(prog, hidden, n):
+def algorithmic_flops_per_point(prog, hidden, n, v=2.0 / 3.0):
     """per residual point and step, 6 forward + 6 adjoint channel-evaluations of the
     circuit, plus (1 fwd + 1 adj) for each of the 2*(1/3) value points; MLPs 2*(3H+Hn+nH+H) per
     channel-evaluation.  Returned per kernel family, per residual point."""
     F = prog.algorithmic_flops()
     mlp_pre = 2 * (3 * hidden + hidden * n)
     mlp_post = 2 * (n * hidden + hidden)
+    # v: value (BC + IC) points per residual point, 2 * (B // 3) / B
     return {
         "circuit_jets_fwd": 6 * F, "circuit_jets_bwd": 6 * F,
         "pre_fwd": 6 * mlp_pre, "pre_bwd": 6 * mlp_pre, "post": 12 * mlp_post,
+        # the fused step's merged launches: residual tiles (6 channels) + value tiles (1 channel) in one kernel
+        "stage_circuit_fwd": (6 + v) * F, "stage_circuit_bwd": (6 + v) * F,
+        "stage_pre_fwd": (6 + v) * mlp_pre, "stage_pre_bwd": (6 + v) * mlp_pre, "stage_post": 2 * (6 + v) * mlp_post,
         "step_total": (13 + 1 / 3) * (F + mlp_pre + mlp_post),
     }
 
@@ -101,6 +105,12 @@ def time_kernels(tr, reps=20):
                                                      d.part_stride, rows_res, d.B_val, 1, st),
         "reduce_rows": lambda: lib.qc_reduce_rows(d.part_dev, d.part_rows_cap, d.part_stride, eng.NP + 3, d.flat_dev, st),
     }
+    # when the step runs its merged form (one launch per stage over value + residual tiles) those are the kernels
+    # it executes: time them through qc_fused_step_stage
+    stages = {"stage_pre_fwd": 0, "stage_circuit_fwd": 1, "stage_post": 2, "stage_circuit_bwd": 3, "stage_pre_bwd": 4}
+    if lib.qc_fused_step_stage(C.byref(d), 0, st) == 0:
+        for name, sid in stages.items():
+            calls[name] = (lambda sid=sid: lib.qc_fused_step_stage(C.byref(d), sid, st))
     out = {}
     for name, fn in calls.items():
         for _ in range(3):
@@ -235,9 +245,10 @@ def main():
     if rank == 0:
         prog = model.quantum_layer.program
         n, H = args["num_qubits"], args["classic_network"][1]
-        flops = algorithmic_flops_per_point(prog, H, n)
+        flops = algorithmic_flops_per_point(prog, H, n, (tr.n_ic + tr.n_bc) / max(tr.B_res, 1))
         kt = time_kernels(tr)
-        dom = max((k for k in kt if k in flops), key=lambda k: kt[k])
+        merged = "stage_circuit_bwd" in kt       # the kernels the step actually launches
+        dom = max((k for k in kt if k in flops and k.startswith("stage_") == merged), key=lambda k: kt[k])
         ach = flops[dom] * tr.B_res / (kt[dom] * 1e-3) / 1e12
         step_ms = dt / a.steps * 1e3
         value = a.steps * global_batch / dt

@@ -186,6 +186,17 @@ typedef struct qc_step_desc {
  * additionally the initial-amplitude jets and their cotangents of both pipelines (required). */
 size_t qc_step_workspace_bytes(const qc_program* prog, int64_t B_res, int64_t B_val);
 
+/* One stage of the step above when it runs in its merged form (2 <= n <= 5, angle encoding, both batches non-empty,
+ * workspace present): each stage is a single launch over the value tiles and the residual tiles together.  For
+ * per-kernel timing; QC_ERR_UNSUPPORTED when the step would take the two-stream form instead. */
+#define QC_STAGE_PRE_FWD 0
+#define QC_STAGE_CIRCUIT_FWD 1
+#define QC_STAGE_POST 2          /* point kernel + weight-gradient kernel */
+#define QC_STAGE_CIRCUIT_BWD 3
+#define QC_STAGE_PRE_BWD 4
+#define QC_STAGE_COUNT 5
+int qc_fused_step_stage(const qc_step_desc* desc, int stage, void* stream);
+
 #define QC_PHASE_GRADS 1
 #define QC_PHASE_UPDATE 2
 #define QC_PHASE_SAMPLE 4 /* fill X_res / X_val first (see qc_sample_collocation) */

@@ -381,6 +381,58 @@ int qc_sample_collocation(float* X_res, int64_t n_res, int64_t off_res, float* X
   return qc_sample_collocation_faces(X_res, n_res, off_res, X_val, n_ic, off_ic, n_bc, off_bc, 0, seed, step, stream);
 }
 
+// ---- merged residual + value stages of the fused step (register family, angle encoding)
+static bool merged_ok(const qc_step_desc* d) {
+  static const bool no_merge = [] { const char* e = getenv("QC_NO_MERGE"); return e && e[0] == '1'; }();
+  return !no_merge && use_reg(d->n) && !d->prog->amplitude && d->B_res > 0 && d->B_val > 0 && d->circ_ws_dev &&
+         d->circ_ws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res) && d->X_res_dev && d->ajets_res_dev &&
+         d->qjets_res_dev && d->qbar_res_dev && d->abar_res_dev && d->X_val_dev && d->ajets_val_dev && d->qjets_val_dev &&
+         d->qbar_val_dev && d->abar_val_dev;
+}
+
+static int merged_stage(const qc_step_desc* d, int stage, hipStream_t st) {
+  const QcLayout L = make_layout(d->H, d->n, d->n_theta);
+  const int64_t rows_res = qc_ceil_div(d->B_res, 64);
+  const QcTrig* trig = (const QcTrig*)d->trig_dev;
+  const float* prm = d->params_dev;
+  float* chi_store = (float*)d->circ_ws_dev;
+  QcPde pde;
+  memcpy(&pde, &d->pde, sizeof(pde));
+  switch (stage) {
+    case QC_STAGE_PRE_FWD:
+      return qc_mlp_pre_fwd_both((const float*)d->X_res_dev, (const float*)d->X_val_dev, prm, L, d->ajets_res_dev,
+                                 d->ajets_val_dev, d->B_res, d->B_val, st);
+    case QC_STAGE_CIRCUIT_FWD:
+      return qc_reg_circ_fwd_both(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, chi_store,
+                                  d->ajets_val_dev, d->qjets_val_dev, d->B_val, st);
+    case QC_STAGE_POST:
+      // abar_* are written only by the adjoint sweep: their heads serve as per-point cotangent scratch here
+      return qc_mlp_post_both(prm, L, pde, (const float*)d->X_res_dev, d->qjets_res_dev, d->abar_res_dev,
+                              d->abar_res_dev + d->B_res, d->qbar_res_dev, 0, d->B_res, (const float*)d->X_val_dev,
+                              d->qjets_val_dev, d->abar_val_dev, d->qbar_val_dev, rows_res, d->B_val, d->part_dev,
+                              d->part_stride, st);
+    case QC_STAGE_CIRCUIT_BWD:
+      return qc_reg_circ_bwd_both(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev, 0, d->B_res,
+                                  chi_store, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev, rows_res, d->B_val,
+                                  d->part_dev + L.oTh, d->part_stride, st);
+    case QC_STAGE_PRE_BWD:
+      return qc_mlp_pre_bwd_both((const float*)d->X_res_dev, (const float*)d->X_val_dev, prm, L, d->abar_res_dev,
+                                 d->abar_val_dev, d->part_dev, d->part_stride, 0, rows_res, d->B_res, d->B_val, st);
+    default: return QC_ERR_ARG;
+  }
+}
+
+int qc_fused_step_stage(const qc_step_desc* d, int stage, void* stream) {
+  if (!d || !d->prog || !d->trig_dev || !d->params_dev || !d->part_dev) return QC_ERR_ARG;
+  if (d->prog->n_qubits != d->n || d->prog->n_params != d->n_theta) return QC_ERR_ARG;
+  if (stage < 0 || stage >= QC_STAGE_COUNT) return QC_ERR_ARG;
+  if (!merged_ok(d)) return QC_ERR_UNSUPPORTED;
+  int rc = check_mlp(d->H, d->n, d->n_theta, d->B_res, 6);
+  if (rc) return rc;
+  if ((rc = merged_stage(d, stage, (hipStream_t)stream))) return rc;
+  return after_launch();
+}
+
 int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream) {
   if (!d || !d->prog || !d->trig_dev || !d->params_dev || !d->part_dev || !d->flat_dev) return QC_ERR_ARG;
   const int n = d->n, H = d->H;
@@ -416,33 +468,12 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
                                           d->sample_bc_face_points, d->sample_seed, d->sample_step, st))) return rc;
   }
   // register family, angle encoding, both pipelines present, final-state store available: every stage is ONE launch
-  // over the residual tiles and the value tiles together (no side stream, 9 launches per step); QC_NO_MERGE=1 keeps
+  // over the value tiles and the residual tiles together (no side stream, 9 launches per step); QC_NO_MERGE=1 keeps
   // the two-stream form below
-  static const bool no_merge = [] { const char* e = getenv("QC_NO_MERGE"); return e && e[0] == '1'; }();
-  const bool merged = (phases & QC_PHASE_GRADS) && !no_merge && use_reg(n) && !amp && d->B_res > 0 && d->B_val > 0 && cws &&
-                      cws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res);
+  const bool merged = (phases & QC_PHASE_GRADS) && merged_ok(d);
   if (merged) {
-    if (!d->X_res_dev || !d->ajets_res_dev || !d->qjets_res_dev || !d->qbar_res_dev || !d->abar_res_dev || !d->X_val_dev ||
-        !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
-      return QC_ERR_ARG;
-    QcPde pde;
-    memcpy(&pde, &d->pde, sizeof(pde));
-    const float* prm = d->params_dev;
-    float* chi_store = (float*)cws;
-    if ((rc = qc_mlp_pre_fwd_both((const float*)d->X_res_dev, (const float*)d->X_val_dev, prm, L, d->ajets_res_dev,
-                                  d->ajets_val_dev, d->B_res, d->B_val, st))) return rc;
-    if ((rc = qc_reg_circ_fwd_both(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, chi_store,
-                                   d->ajets_val_dev, d->qjets_val_dev, d->B_val, st))) return rc;
-    // abar_* are written only by the adjoint sweep below: their heads serve as per-point cotangent scratch here
-    if ((rc = qc_mlp_post_both(prm, L, pde, (const float*)d->X_res_dev, d->qjets_res_dev, d->abar_res_dev,
-                               d->abar_res_dev + d->B_res, d->qbar_res_dev, 0, d->B_res, (const float*)d->X_val_dev,
-                               d->qjets_val_dev, d->abar_val_dev, d->qbar_val_dev, rows_res, d->B_val, d->part_dev,
-                               d->part_stride, st))) return rc;
-    if ((rc = qc_reg_circ_bwd_both(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qbar_res_dev, d->abar_res_dev, 0, d->B_res,
-                                   chi_store, d->ajets_val_dev, d->qbar_val_dev, d->abar_val_dev, rows_res, d->B_val,
-                                   d->part_dev + L.oTh, d->part_stride, st))) return rc;
-    if ((rc = qc_mlp_pre_bwd_both((const float*)d->X_res_dev, (const float*)d->X_val_dev, prm, L, d->abar_res_dev,
-                                  d->abar_val_dev, d->part_dev, d->part_stride, 0, rows_res, d->B_res, d->B_val, st))) return rc;
+    for (int stage = 0; stage < QC_STAGE_COUNT; ++stage)
+      if ((rc = merged_stage(d, stage, st))) return rc;
     if ((rc = after_launch())) return rc;
   }
   if ((phases & QC_PHASE_GRADS) && !merged) {

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "libqcpinn_hip.so")
 QC_PHASE_GRADS = 1
 QC_PHASE_UPDATE = 2
 QC_PHASE_SAMPLE = 4
+QC_STAGE_PRE_FWD, QC_STAGE_CIRCUIT_FWD, QC_STAGE_POST, QC_STAGE_CIRCUIT_BWD, QC_STAGE_PRE_BWD = range(5)
 
 # every symbol include/qcpinn_hip.h declares
 EXPORTS = (
@@ -24,6 +25,7 @@ EXPORTS = (
     "qc_circuit_workspace_bytes", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_forward_jets_keep", "qc_backward_jets_kept", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
     "qc_sample_collocation", "qc_sample_collocation_faces", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
+    "qc_fused_step_stage",
 )
 
 
