@@ -301,10 +301,22 @@ __device__ __forceinline__ void k_post_body(const int64_t bid, const float* __re
   const int m0 = wave * hq, m1 = (m0 + hq) < L.H ? (m0 + hq) : L.H;
 
   float ub0 = 0.f, gsc = 0.f;  // cotangent of u, and of the residual
+  // MODE 2: the reverse pass is linear in its single non-zero cotangent (the residual's for residual points,
+  // u's for value points), so it is accumulated for a UNIT cotangent inside the forward loop and scaled
+  // afterwards - the pre-activations and tanh are formed once per hidden unit, not twice.
+  float qbu[MODE == 2 ? NCH : 1][N];
+  if constexpr (MODE == 2) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) qbu[c][i] = 0.f;
+  }
   if constexpr (MODE == 0 || MODE == 2) {
     float u[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) u[c] = 0.f;
+    float ub_unit[NCH];
+    expand_ub<NCH>(ub_unit, NCH == 6 ? 0.f : 1.f, NCH == 6 ? 1.f : 0.f, pde);
     for (int m = m0; m < m1; ++m) {
       float g[NCH];
 #pragma unroll
@@ -324,6 +336,16 @@ __device__ __forceinline__ void k_post_body(const int64_t bid, const float* __re
         u[3] = fmaf(w4, d1 * g[3], u[3]);
         u[4] = fmaf(w4, d2 * g[2] * g[2] + d1 * g[4], u[4]);
         u[5] = fmaf(w4, d2 * g[3] * g[3] + d1 * g[5], u[5]);
+      }
+      if constexpr (MODE == 2) {
+        float gb[NCH], gw4;
+        post_cotangents<N, NCH>(gb, gw4, g, ub_unit, z, w4);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const float w3 = W3[m * N + i];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) qbu[c][i] = fmaf(w3, gb[c], qbu[c][i]);
+        }
       }
     }
 #pragma unroll
@@ -385,7 +407,19 @@ __device__ __forceinline__ void k_post_body(const int64_t bid, const float* __re
     ub0 = (live && in_ubar) ? in_ubar[pc] : 0.f;
     if constexpr (NCH == 6) gsc = (live && in_rbar) ? in_rbar[pc] : 0.f;
   }
-  if constexpr (MODE == 1 || MODE == 2) {
+  if constexpr (MODE == 2) {
+    const float scale = NCH == 6 ? gsc : ub0;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) s_buf[wave][c * N + i][lane] = scale * qbu[c][i];
+    __syncthreads();
+    if (live) {
+      for (int f = wave; f < NCH * N; f += QC_MS)
+        qbar[(int64_t)f * B + p] = (s_buf[0][f][lane] + s_buf[1][f][lane]) + (s_buf[2][f][lane] + s_buf[3][f][lane]);
+    }
+  }
+  if constexpr (MODE == 1) {
     float ub[NCH];
     expand_ub<NCH>(ub, ub0, gsc, pde);
     float qb[NCH][N];
