@@ -390,7 +390,7 @@ static bool merged_ok(const qc_step_desc* d) {
          d->qbar_val_dev && d->abar_val_dev;
 }
 
-static int merged_stage(const qc_step_desc* d, int stage, hipStream_t st) {
+static int merged_stage(const qc_step_desc* d, int stage, hipStream_t st, bool draw = false) {
   const QcLayout L = make_layout(d->H, d->n, d->n_theta);
   const int64_t rows_res = qc_ceil_div(d->B_res, 64);
   const QcTrig* trig = (const QcTrig*)d->trig_dev;
@@ -400,8 +400,9 @@ static int merged_stage(const qc_step_desc* d, int stage, hipStream_t st) {
   memcpy(&pde, &d->pde, sizeof(pde));
   switch (stage) {
     case QC_STAGE_PRE_FWD:
-      return qc_mlp_pre_fwd_both((const float*)d->X_res_dev, (const float*)d->X_val_dev, prm, L, d->ajets_res_dev,
-                                 d->ajets_val_dev, d->B_res, d->B_val, st);
+      return qc_mlp_pre_fwd_both((float*)d->X_res_dev, (float*)d->X_val_dev, prm, L, d->ajets_res_dev, d->ajets_val_dev,
+                                 d->B_res, d->B_val, draw ? 1 : 0, d->n_ic, d->sample_off_res, d->sample_off_ic,
+                                 d->sample_off_bc, d->sample_bc_face_points, d->sample_seed, d->sample_step, st);
     case QC_STAGE_CIRCUIT_FWD:
       return qc_reg_circ_fwd_both(d->prog, trig, d->umat_dev, d->ajets_res_dev, d->qjets_res_dev, d->B_res, chi_store,
                                   d->ajets_val_dev, d->qjets_val_dev, d->B_val, st);
@@ -462,7 +463,9 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
     if (cws_bytes == 0) cws = nullptr;
   }
 
-  if (phases & QC_PHASE_SAMPLE) {
+  // (in the merged form below the first stage draws the points itself)
+  const bool draw_in_stage = (phases & QC_PHASE_SAMPLE) && (phases & QC_PHASE_GRADS) && merged_ok(d);
+  if ((phases & QC_PHASE_SAMPLE) && !draw_in_stage) {
     if ((rc = qc_sample_collocation_faces((float*)d->X_res_dev, d->B_res, d->sample_off_res, (float*)d->X_val_dev, d->n_ic,
                                           d->sample_off_ic, d->B_val - d->n_ic, d->sample_off_bc,
                                           d->sample_bc_face_points, d->sample_seed, d->sample_step, st))) return rc;
@@ -473,7 +476,7 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
   const bool merged = (phases & QC_PHASE_GRADS) && merged_ok(d);
   if (merged) {
     for (int stage = 0; stage < QC_STAGE_COUNT; ++stage)
-      if ((rc = merged_stage(d, stage, st))) return rc;
+      if ((rc = merged_stage(d, stage, st, draw_in_stage && stage == QC_STAGE_PRE_FWD))) return rc;
     if ((rc = after_launch())) return rc;
   }
   if ((phases & QC_PHASE_GRADS) && !merged) {

@@ -73,8 +73,9 @@ int qc_reg_circ_bwd_both(const qc_program* pg, const QcTrig* trig, const float* 
                          const float* qbar, float* abar, int64_t row0_r, int64_t Br, const float* chi_store,
                          const float* angles, const float* cot, float* d_angles, int64_t row0_v, int64_t Bv, float* part,
                          int64_t part_stride, hipStream_t st);
-int qc_mlp_pre_fwd_both(const float* Xr, const float* Xv, const float* prm, QcLayout L, float* ajr, float* ajv,
-                        int64_t Br, int64_t Bv, hipStream_t st);
+int qc_mlp_pre_fwd_both(float* Xr, float* Xv, const float* prm, QcLayout L, float* ajr, float* ajv, int64_t Br, int64_t Bv,
+                        int draw, int64_t n_ic, int64_t off_res, int64_t off_ic, int64_t off_bc, int64_t face_pts,
+                        uint64_t seed, uint64_t step, hipStream_t st);
 int qc_mlp_pre_bwd_both(const float* Xr, const float* Xv, const float* prm, QcLayout L, const float* abr, const float* abv,
                         float* part, int64_t part_stride, int64_t row0_r, int64_t row0_v, int64_t Br, int64_t Bv,
                         hipStream_t st);

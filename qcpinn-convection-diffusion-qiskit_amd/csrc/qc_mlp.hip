@@ -18,6 +18,7 @@
 // NCH = 6 : residual points, channels {value, d/dt, d/dx, d/dy, d2/dx2, d2/dy2};
 // NCH = 1 : boundary / initial-condition points, value channel only.
 #include "qc_internal.h"
+#include "qc_philox.h"
 
 namespace {
 
@@ -57,13 +58,30 @@ constexpr int QC_MS = 4;
 
 template <int N, int NCH>
 __device__ __forceinline__ void k_pre_fwd_body(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm,
-                                                 QcLayout L, float* __restrict__ ajets, int64_t B) {
+                                                 QcLayout L, float* __restrict__ ajets, int64_t B,
+                                                 const QcDraw* __restrict__ draw = nullptr, float* __restrict__ Xout = nullptr) {
   __shared__ float s_part[QC_MS][NCH * N][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t p = (int64_t)bid * 64 + lane;
   const int64_t pc = p < B ? p : B - 1;
-  const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
+  float t, x, y;
+  if (draw != nullptr && draw->enabled) {
+    // the step's sampler folded into its first stage: this tile draws its own points (same Philox counters as
+    // k_sample) and wave 0 leaves them in X for the later stages
+    if (NCH == 6) qc_draw_point(0, draw->off_res + pc, 0, draw->seed, draw->step, t, x, y);
+    else if (pc < draw->n_ic) qc_draw_point(1, draw->off_ic + pc, 0, draw->seed, draw->step, t, x, y);
+    else qc_draw_point(2, draw->off_bc + (pc - draw->n_ic), draw->face_pts, draw->seed, draw->step, t, x, y);
+    if (wave == 0 && p < B) {
+      Xout[p * 3 + 0] = t;
+      Xout[p * 3 + 1] = x;
+      Xout[p * 3 + 2] = y;
+    }
+  } else {
+    t = X[pc * 3 + 0];
+    x = X[pc * 3 + 1];
+    y = X[pc * 3 + 2];
+  }
   float acc[NCH][N];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
@@ -568,11 +586,11 @@ __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, 
 // (the lighter value tiles first, so the launch ends on full-occupancy residual tiles; block-uniform branch) removes the side stream, its two
 // cross-queue event waits (~7 us of idle queue each) and 6 of the step's 15 launches.
 template <int N>
-__global__ void __launch_bounds__(256) k_pre_fwd_both(const float* __restrict__ Xr, const float* __restrict__ Xv,
+__global__ void __launch_bounds__(256) k_pre_fwd_both(float* __restrict__ Xr, float* __restrict__ Xv,
                                                       const float* __restrict__ prm, QcLayout L, float* __restrict__ ajr,
-                                                      float* __restrict__ ajv, int64_t Br, int64_t Bv, int n_val) {
-  if ((int)blockIdx.x >= n_val) k_pre_fwd_body<N, 6>(blockIdx.x - n_val, Xr, prm, L, ajr, Br);
-  else k_pre_fwd_body<N, 1>(blockIdx.x, Xv, prm, L, ajv, Bv);
+                                                      float* __restrict__ ajv, int64_t Br, int64_t Bv, int n_val, QcDraw draw) {
+  if ((int)blockIdx.x >= n_val) k_pre_fwd_body<N, 6>(blockIdx.x - n_val, Xr, prm, L, ajr, Br, &draw, Xr);
+  else k_pre_fwd_body<N, 1>(blockIdx.x, Xv, prm, L, ajv, Bv, &draw, Xv);
 }
 
 template <int N>
@@ -708,11 +726,17 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
 }
 
 // ------------------------------------------------------------------ merged residual + value launches (fused step)
-int qc_mlp_pre_fwd_both(const float* Xr, const float* Xv, const float* prm, QcLayout L, float* ajr, float* ajv,
-                        int64_t Br, int64_t Bv, hipStream_t st) {
+// draw_*: when `draw` != 0 the launch first draws its own points (qc_sample_collocation_faces semantics) into Xr / Xv
+int qc_mlp_pre_fwd_both(float* Xr, float* Xv, const float* prm, QcLayout L, float* ajr, float* ajv, int64_t Br, int64_t Bv,
+                        int draw, int64_t n_ic, int64_t off_res, int64_t off_ic, int64_t off_bc, int64_t face_pts,
+                        uint64_t seed, uint64_t step, hipStream_t st) {
   const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 64);
+  QcDraw dr;
+  dr.enabled = draw;
+  dr.n_ic = n_ic; dr.off_res = off_res; dr.off_ic = off_ic; dr.off_bc = off_bc; dr.face_pts = face_pts;
+  dr.seed = seed; dr.step = step;
 #define CALL(NN) \
-  hipLaunchKernelGGL((k_pre_fwd_both<NN>), dim3(nr + nv), dim3(256), 0, st, Xr, Xv, prm, L, ajr, ajv, Br, Bv, nv);
+  hipLaunchKernelGGL((k_pre_fwd_both<NN>), dim3(nr + nv), dim3(256), 0, st, Xr, Xv, prm, L, ajr, ajv, Br, Bv, nv, dr);
   QC_MLP_DISPATCH(L.n, CALL)
 #undef CALL
   return QC_OK;

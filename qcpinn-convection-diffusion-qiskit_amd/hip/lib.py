@@ -109,6 +109,8 @@ def load() -> C.CDLL:
     lib.qc_reduce_rows.argtypes = [fp, i64, i64, i32, fp, vp]
     lib.qc_adam_step.argtypes = [fp, i32, fp, fp, fp, vp, C.POINTER(QcOptHyper), fp, i32, vp, i32, vp, vp]
     lib.qc_sample_collocation.argtypes = [fp, i64, i64, fp, i64, i64, i64, i64, C.c_uint64, C.c_uint64, vp]
+    lib.qc_sample_collocation_faces.argtypes = [fp, i64, i64, fp, i64, i64, i64, i64, i64, C.c_uint64, C.c_uint64, vp]
+    lib.qc_fused_step_stage.argtypes = [C.POINTER(QcStepDesc), i32, vp]
     lib.qc_step_workspace_bytes.restype = C.c_size_t
     lib.qc_step_workspace_bytes.argtypes = [vp, i64, i64]
     lib.qc_program_set_encoding.argtypes = [vp, i32]

@@ -194,6 +194,39 @@ def test_device_sampler_boxes_and_sharding(gpu_device):
     assert not np.array_equal(Xr.cpu().numpy(), xr)
 
 
+@pytest.mark.parametrize("merge", ["1", "0"])
+def test_fused_step_draws_the_same_points_as_the_sampler_entry_point(merge, gpu_device, tmp_path):
+    """The merged step folds the sampler into its first stage: the points it leaves in X_res / X_val must be
+    the ones qc_sample_collocation_faces draws for the same (seed, step, offsets); the two-stream form
+    (QC_NO_MERGE=1, child process) launches k_sample itself."""
+    if merge == "0":
+        import subprocess, sys
+        env = dict(os.environ, QC_NO_MERGE="1")
+        code = ("import pytest,sys; sys.exit(pytest.main(['-q','-x','-m','gpu', "
+                "'tests/test_gpu_solver.py::test_fused_step_draws_the_same_points_as_the_sampler_entry_point[1]']))")
+        assert subprocess.run([sys.executable, "-c", code], env=env, cwd=os.path.dirname(os.path.dirname(__file__))).returncode == 0
+        return
+    L = pkg("hip.lib")
+    lib = L.load()
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    trainer = pkg("trainer.diffusion_train")
+    torch.manual_seed(4)
+    model = Solver(base_args(), Log(tmp_path), device=gpu_device)
+    tr = trainer.FusedTrainer(model, 1000, capacity=4)
+    for _ in range(2):
+        tr.sample()
+        tr.step()
+    torch.cuda.synchronize()
+    d = tr.fs.desc
+    st = torch.cuda.current_stream(gpu_device).cuda_stream
+    Xr = torch.empty_like(tr.fs.X_res)
+    Xv = torch.empty_like(tr.fs.X_val)
+    L.check(lib.qc_sample_collocation_faces(Xr.data_ptr(), d.B_res, d.sample_off_res, Xv.data_ptr(), d.n_ic, d.sample_off_ic,
+                                            d.B_val - d.n_ic, d.sample_off_bc, d.sample_bc_face_points, d.sample_seed,
+                                            d.sample_step, st))
+    assert torch.equal(Xr, tr.fs.X_res) and torch.equal(Xv, tr.fs.X_val)
+
+
 def test_training_with_device_sampler_reduces_loss(gpu_device, tmp_path):
     Solver = pkg("nn.DVPDESolver").DVPDESolver
     trainer = pkg("trainer.diffusion_train")
