@@ -580,6 +580,121 @@ __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, 
   k_post_wg_body<N, NCH>(blockIdx.x, prm, L, pde, qjets, ubar, rbar, part, part_stride, row0, B, HB, PS);
 }
 
+// ================================================================== value tiles, one wave per tile
+// In the merged launches a value tile (64 boundary / initial points, value channel only) is too little work to
+// split four ways with two LDS round trips: here each of a block's 4 waves owns one whole tile (all hidden units,
+// scalar weights, no LDS, no barrier).  Same arithmetic as the NCH = 1 instances of the kernels above; the four
+// per-quarter partial sums are still formed and added as (p0 + p1) + (p2 + p3) (same association as the m-split form).
+template <int N>
+__device__ __forceinline__ void k_pre_fwd_value4(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm,
+                                                 QcLayout L, float* __restrict__ ajets, int64_t B,
+                                                 const QcDraw* __restrict__ draw, float* __restrict__ Xout) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = bid * 4 + wave;
+  if (tile * 64 >= B) return;
+  const int64_t p = tile * 64 + lane;
+  const int64_t pc = p < B ? p : B - 1;
+  float t, x, y;
+  if (draw != nullptr && draw->enabled) {
+    if (pc < draw->n_ic) qc_draw_point(1, draw->off_ic + pc, 0, draw->seed, draw->step, t, x, y);
+    else qc_draw_point(2, draw->off_bc + (pc - draw->n_ic), draw->face_pts, draw->seed, draw->step, t, x, y);
+    if (p < B) {
+      Xout[p * 3 + 0] = t;
+      Xout[p * 3 + 1] = x;
+      Xout[p * 3 + 2] = y;
+    }
+  } else {
+    t = X[pc * 3 + 0];
+    x = X[pc * 3 + 1];
+    y = X[pc * 3 + 2];
+  }
+  const float* W1 = prm + L.oW1;
+  const float* b1 = prm + L.ob1;
+  const float* W2 = prm + L.oW2;
+  const int hq = (L.H + QC_MS - 1) / QC_MS;
+  float part[QC_MS][N];
+#pragma unroll
+  for (int k = 0; k < QC_MS; ++k) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) part[k][i] = 0.f;
+    const int m0 = k * hq, m1 = (m0 + hq) < L.H ? (m0 + hq) : L.H;
+    for (int m = m0; m < m1; ++m) {
+      const float h = fmaf(W1[3 * m], t, fmaf(W1[3 * m + 1], x, fmaf(W1[3 * m + 2], y, b1[m])));
+      const float z = qc_tanh(h);
+#pragma unroll
+      for (int i = 0; i < N; ++i) part[k][i] = fmaf(W2[i * L.H + m], z, part[k][i]);
+    }
+  }
+  if (p < B) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      ajets[(int64_t)i * B + p] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) + prm[L.ob2 + i];
+  }
+}
+
+// fused (mode 2) post stage of a value tile: u, squared error against the analytic target, cotangent of <Z>
+template <int N>
+__device__ __forceinline__ void k_post_value4(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm,
+                                              QcLayout L, QcPde pde, const float* __restrict__ qjets,
+                                              float* __restrict__ out_u, float* __restrict__ qbar, float* __restrict__ part,
+                                              int64_t part_stride, int64_t row0, int64_t B) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = bid * 4 + wave;
+  if (tile * 64 >= B) return;
+  const int64_t p = tile * 64 + lane;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+  float q[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) q[i] = qjets[(int64_t)i * B + pc];
+  const float* W3 = prm + L.oW3;
+  const float* b3 = prm + L.ob3;
+  const float* W4 = prm + L.oW4;
+  const int hq = (L.H + QC_MS - 1) / QC_MS;
+  float up[QC_MS], qbu[QC_MS][N];
+#pragma unroll
+  for (int k = 0; k < QC_MS; ++k) {
+    up[k] = 0.f;
+#pragma unroll
+    for (int i = 0; i < N; ++i) qbu[k][i] = 0.f;
+    const int m0 = k * hq, m1 = (m0 + hq) < L.H ? (m0 + hq) : L.H;
+    for (int m = m0; m < m1; ++m) {
+      float g = b3[m];
+#pragma unroll
+      for (int i = 0; i < N; ++i) g = fmaf(W3[m * N + i], q[i], g);
+      const float z = qc_tanh(g);
+      const float w4 = W4[m];
+      up[k] = fmaf(w4, z, up[k]);
+      const float gb = (1.f - z * z) * w4;          // post_cotangents<N, 1> for a unit cotangent of u
+#pragma unroll
+      for (int i = 0; i < N; ++i) qbu[k][i] = fmaf(W3[m * N + i], gb, qbu[k][i]);
+    }
+  }
+  const float u = ((up[0] + up[1]) + (up[2] + up[3])) + prm[L.ob4];
+  const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
+  const bool seg_a = p < pde.n_seg_a;
+  const float target = pde.problem == QC_PB_PURE_DIFFUSION ? (seg_a ? analytic_u_diffusion(t, x, y, pde.D) : 0.f)
+                                                           : analytic_u(t, x, y);
+  const float e = live ? u - target : 0.f;
+  const float ub0 = (seg_a ? pde.w_val_a : pde.w_val_b) * e;
+  const float la = qc_wave_sum_to_lane63(seg_a ? e * e * pde.inv_n_a : 0.f);
+  const float lb = qc_wave_sum_to_lane63(seg_a ? 0.f : e * e * pde.inv_n_b);
+  if (lane == 63) {
+    float* row = part + (row0 + tile) * part_stride;
+    row[L.NP + 0] = 0.f;
+    row[L.NP + 1] = lb;  // column order: residual, BC, IC; segment a = IC, b = BC
+    row[L.NP + 2] = la;
+  }
+  if (live) {
+    out_u[p] = ub0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      qbar[(int64_t)i * B + p] = (ub0 * qbu[0][i] + ub0 * qbu[1][i]) + (ub0 * qbu[2][i] + ub0 * qbu[3][i]);
+  }
+}
+
 // ================================================================== residual + value tiles in ONE launch
 // The fused step's two pipelines (65 536 residual points with 6 channels, 2 x 21 845 boundary / initial points with
 // the value channel) are independent until the row reduction.  Launching each stage once over the blocks of BOTH
@@ -590,7 +705,7 @@ __global__ void __launch_bounds__(256) k_pre_fwd_both(float* __restrict__ Xr, fl
                                                       const float* __restrict__ prm, QcLayout L, float* __restrict__ ajr,
                                                       float* __restrict__ ajv, int64_t Br, int64_t Bv, int n_val, QcDraw draw) {
   if ((int)blockIdx.x >= n_val) k_pre_fwd_body<N, 6>(blockIdx.x - n_val, Xr, prm, L, ajr, Br, &draw, Xr);
-  else k_pre_fwd_body<N, 1>(blockIdx.x, Xv, prm, L, ajv, Bv, &draw, Xv);
+  else k_pre_fwd_value4<N>(blockIdx.x, Xv, prm, L, ajv, Bv, &draw, Xv);
 }
 
 template <int N>
@@ -619,8 +734,7 @@ __global__ void __launch_bounds__(256) k_post_both(const float* __restrict__ prm
     k_post_body<N, 6, 2>(blockIdx.x - n_val, r.X, prm, L, pde, r.qjets, r.ub, r.rb, nullptr, nullptr, r.qbar, part, part_stride,
                          r.row0, r.B);
   else
-    k_post_body<N, 1, 2>(blockIdx.x, v.X, prm, L, pde, v.qjets, v.ub, nullptr, nullptr, nullptr, v.qbar, part,
-                         part_stride, v.row0, v.B);
+    k_post_value4<N>(blockIdx.x, v.X, prm, L, pde, v.qjets, v.ub, v.qbar, part, part_stride, v.row0, v.B);
 }
 
 template <int N>
@@ -730,7 +844,7 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
 int qc_mlp_pre_fwd_both(float* Xr, float* Xv, const float* prm, QcLayout L, float* ajr, float* ajv, int64_t Br, int64_t Bv,
                         int draw, int64_t n_ic, int64_t off_res, int64_t off_ic, int64_t off_bc, int64_t face_pts,
                         uint64_t seed, uint64_t step, hipStream_t st) {
-  const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 64);
+  const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(qc_ceil_div(Bv, 64), 4);   // value tiles: 4 per block, one per wave
   QcDraw dr;
   dr.enabled = draw;
   dr.n_ic = n_ic; dr.off_res = off_res; dr.off_ic = off_ic; dr.off_bc = off_bc; dr.face_pts = face_pts;
@@ -767,9 +881,10 @@ int qc_mlp_post_both(const float* prm, QcLayout L, QcPde pde, const float* Xr, c
   int HB, PS, threads;
   hidden_geometry(L.H, &HB, &PS, &threads);
   const size_t sh = (size_t)PS * (L.n + 2) * HB * sizeof(float);
+  const int nv4 = qc_ceil_div(nv, 4);   // point kernel: 4 value tiles per block, one per wave
   const QcPostSeg r = {Xr, qjr, ubr, rbr, qbr, row0_r, Br}, v = {Xv, qjv, ubv, nullptr, qbv, row0_v, Bv};
 #define CALL(NN)                                                                                                      \
-  hipLaunchKernelGGL((k_post_both<NN>), dim3(nr + nv), dim3(256), 0, st, prm, L, pde, r, v, part, part_stride, nv);   \
+  hipLaunchKernelGGL((k_post_both<NN>), dim3(nr + nv4), dim3(256), 0, st, prm, L, pde, r, v, part, part_stride, nv4); \
   hipLaunchKernelGGL((k_post_wg_both<NN>), dim3(nr + nv), dim3(threads), sh, st, prm, L, pde, r, v, part, part_stride, \
                      HB, PS, nv);
   QC_MLP_DISPATCH(L.n, CALL)
