@@ -120,6 +120,7 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
                  : ((n_qubits >= 6 && n_qubits <= 8) ? qc_wave_match_static(p) : -1);
   p->hbm_plan = nullptr;
   p->amplitude = 0;
+  p->n_diag_runs = qc_count_diag_runs(h, n_gates, n_qubits);
   p->lead_rx = n_gates >= n_qubits ? 1 : 0;   // RX(p_w) right after the embedding RX(a_w), wire by wire, distinct slots
   for (int g = 0; g < n_qubits && p->lead_rx; ++g)
     if (h[g].op != QC_RX || h[g].ba != n_qubits - 1 - g || h[g].slot < 0) p->lead_rx = 0;
@@ -182,7 +183,9 @@ int qc_amp_backward(const float* ajets, const float* ubar, float* abar, int n, i
   return after_launch();
 }
 
-size_t qc_trig_bytes(const qc_program* p) { return p ? sizeof(QcTrig) * (size_t)p->n_gates : 0; }
+size_t qc_trig_bytes(const qc_program* p) {
+  return p ? sizeof(QcTrig) * ((size_t)p->n_gates + (size_t)p->n_diag_runs * ((size_t)1 << p->n_qubits)) : 0;
+}
 
 int qc_prepare_gates(const qc_program* p, const float* theta, void* trig, void* stream) {
   if (!p || !trig || (p->n_params > 0 && !theta)) return QC_ERR_ARG;

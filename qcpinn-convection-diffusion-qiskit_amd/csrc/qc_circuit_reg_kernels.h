@@ -104,7 +104,7 @@ struct StatProg {
     constexpr SGate g = SP::g[I];
     t.c[I] = 1.f;
     t.s[I] = 0.f;
-    if constexpr (g.op != QC_U4 && g.slot >= 0) {
+    if constexpr (g.op != QC_U4 && g.slot >= 0 && !fused(I)) {
       t.c[I] = trig[I].c;
       t.s[I] = trig[I].s;
     }
@@ -115,48 +115,115 @@ struct StatProg {
     (load_one<Is>(t, trig), ...);
     __builtin_amdgcn_sched_barrier(0);
   }
+  // ---- runs of >= 2 consecutive diagonal gates (RZ / CRZ) are ONE table multiply (tables: qc_fill_diag_tables)
+  static constexpr bool is_diag(int i) { return i >= 0 && i < SP::G && (SP::g[i].op == QC_RZ || SP::g[i].op == QC_CRZ); }
+  static constexpr int run_begin(int i) { while (is_diag(i - 1)) --i; return i; }
+  static constexpr int run_end(int i) { while (is_diag(i)) ++i; return i; }          // one past the last gate
+  static constexpr bool fused(int i) { return is_diag(i) && run_end(i) - run_begin(i) >= 2; }
+  static constexpr int run_ordinal(int i) {
+    int r = 0;
+    for (int g = 0; g < run_begin(i);) {
+      if (!is_diag(g)) { ++g; continue; }
+      const int e = run_end(g);
+      if (e - g >= 2) ++r;
+      g = e;
+    }
+    return r;
+  }
+  template <int I, bool ADJ, int K>
+  __device__ static __forceinline__ void apply_table(SV<N> (&v)[K], const QcTrig* __restrict__ trig) {
+    const QcTrig* tab = trig + SP::G + run_ordinal(I) * (1 << N);
+#pragma unroll
+    for (int k = 0; k < (1 << N); ++k) {
+      const float dr = tab[k].c, di = ADJ ? -tab[k].s : tab[k].s;
+#pragma unroll
+      for (int q = 0; q < K; ++q) {
+        const float ar = v[q].re[k], ai = v[q].im[k];
+        v[q].re[k] = fmaf(-di, ai, dr * ar);
+        v[q].im[k] = fmaf(di, ar, dr * ai);
+      }
+    }
+  }
+  // gradient terms of the gates H, H+1, ..., E-1 of one run from t[k] = Im(conj(lam_k) chi_k) (invariant under
+  // the other diagonal gates of the run): signed by the target bit, masked by the control bit
+  template <int H, int E>
+  __device__ static __forceinline__ void run_grads(const float (&t)[1 << N], float (&gacc)[SP::P > 0 ? SP::P : 1]) {
+    if constexpr (H < E) {
+      constexpr SGate g = SP::g[H];
+      constexpr bool ctl = g.op == QC_CRZ;
+      constexpr int tb = ctl ? g.bb : g.ba;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < (1 << N); ++k) {
+        if (ctl && !((k >> g.ba) & 1)) continue;
+        acc += ((k >> tb) & 1) ? -t[k] : t[k];
+      }
+      if constexpr (g.slot >= 0) gacc[g.slot] += qc_wave_sum_to_lane63(acc);
+      run_grads<H + 1, E>(t, gacc);
+    }
+  }
   template <int I>
   __device__ static __forceinline__ void fwd_one(SV<N> (&v)[1], const Trig& t, const float* __restrict__ umat,
-                                                 int absorb) {
+                                                 int absorb, const QcTrig* __restrict__ trig) {
     constexpr SGate g = SP::g[I];
     if constexpr (I < N) {
       if (absorb) return;   // leading RX layer folded into the embedding angles
     }
-    qc_static_gate<N, 1, false, g.op, g.ba, g.bb, g.slot>(v, t.c[I], t.s[I], umat);
-    __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from interleaving whole gates (register pressure)
+    if constexpr (fused(I)) {
+      if constexpr (I == run_begin(I)) {
+        apply_table<I, false, 1>(v, trig);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      qc_static_gate<N, 1, false, g.op, g.ba, g.bb, g.slot>(v, t.c[I], t.s[I], umat);
+      __builtin_amdgcn_sched_barrier(0);   // keep the scheduler from interleaving whole gates (register pressure)
+    }
   }
   template <int... Is>
   __device__ static __forceinline__ void fwd_all(SV<N> (&v)[1], const Trig& t, const float* __restrict__ umat,
-                                                 int absorb, std::integer_sequence<int, Is...>) {
-    (fwd_one<Is>(v, t, umat, absorb), ...);
+                                                 int absorb, const QcTrig* __restrict__ trig,
+                                                 std::integer_sequence<int, Is...>) {
+    (fwd_one<Is>(v, t, umat, absorb, trig), ...);
   }
   __device__ static __forceinline__ void fwd(SV<N> (&v)[1], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
                                              const float* __restrict__ umat, int, int absorb) {
     Trig t;
     load_all(t, trig, std::make_integer_sequence<int, SP::G>{});
-    fwd_all(v, t, umat, absorb, std::make_integer_sequence<int, SP::G>{});
+    fwd_all(v, t, umat, absorb, trig, std::make_integer_sequence<int, SP::G>{});
   }
   // Reverse sweep.  Parameter slots are compile-time constants here, so the wave totals of the
   // gradient terms stay in registers (gacc[slot], valid in lane 63) and reach LDS once, after the
   // sweep, instead of one LDS read-modify-write round trip per gate.
   template <int J>
   __device__ static __forceinline__ void bwd_one(SV<N> (&cl)[2], const Trig& t, const float* __restrict__ umat,
-                                                 float (&gacc)[SP::P > 0 ? SP::P : 1], int absorb) {
+                                                 float (&gacc)[SP::P > 0 ? SP::P : 1], int absorb,
+                                                 const QcTrig* __restrict__ trig) {
     constexpr int I = SP::G - 1 - J;
     constexpr SGate g = SP::g[I];
     if constexpr (I < N) {
       if (absorb) return;
     }
-    if constexpr (g.op != QC_U4 && g.slot >= 0)
-      gacc[g.slot] += qc_wave_sum_to_lane63(qc_static_grad<N, g.op, g.ba, g.bb>(cl[1], cl[0]));
-    qc_static_gate<N, 2, true, g.op, g.ba, g.bb, g.slot>(cl, t.c[I], t.s[I], umat);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (fused(I)) {
+      if constexpr (I == run_end(I) - 1) {   // first gate of the run met by the reverse sweep
+        float tk[1 << N];
+#pragma unroll
+        for (int k = 0; k < (1 << N); ++k) tk[k] = cl[1].re[k] * cl[0].im[k] - cl[1].im[k] * cl[0].re[k];
+        run_grads<run_begin(I), run_end(I)>(tk, gacc);
+        apply_table<I, true, 2>(cl, trig);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      if constexpr (g.op != QC_U4 && g.slot >= 0)
+        gacc[g.slot] += qc_wave_sum_to_lane63(qc_static_grad<N, g.op, g.ba, g.bb>(cl[1], cl[0]));
+      qc_static_gate<N, 2, true, g.op, g.ba, g.bb, g.slot>(cl, t.c[I], t.s[I], umat);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   template <int... Js>
   __device__ static __forceinline__ void bwd_all(SV<N> (&cl)[2], const Trig& t, const float* __restrict__ umat,
                                                  float (&gacc)[SP::P > 0 ? SP::P : 1], int absorb,
-                                                 std::integer_sequence<int, Js...>) {
-    (bwd_one<Js>(cl, t, umat, gacc, absorb), ...);
+                                                 const QcTrig* __restrict__ trig, std::integer_sequence<int, Js...>) {
+    (bwd_one<Js>(cl, t, umat, gacc, absorb, trig), ...);
   }
   __device__ static __forceinline__ void bwd(SV<N> (&cl)[2], const QcGate* __restrict__, const QcTrig* __restrict__ trig,
                                              const float* __restrict__ umat, int, float* __restrict__ acc_wave,
@@ -166,7 +233,7 @@ struct StatProg {
     for (int k = 0; k < (SP::P > 0 ? SP::P : 1); ++k) gacc[k] = 0.f;
     Trig t;
     load_all(t, trig, std::make_integer_sequence<int, SP::G>{});
-    bwd_all(cl, t, umat, gacc, absorb, std::make_integer_sequence<int, SP::G>{});
+    bwd_all(cl, t, umat, gacc, absorb, trig, std::make_integer_sequence<int, SP::G>{});
 #pragma unroll
     for (int k = 0; k < SP::P; ++k)
       if (lane == 63) acc_wave[k] += gacc[k];   // lane 63 holds the wave totals

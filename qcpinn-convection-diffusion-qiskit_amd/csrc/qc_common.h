@@ -41,6 +41,8 @@ struct qc_program {
   void* hbm_plan;   // QcHbmPlan* for n >= 9 (staged execution), else null
   int amplitude;    // 1: amplitude encoding (initial state given directly), 0: RX angle embedding
   int lead_rx;      // 1: gates 0..n-1 are RX on wires 0..n-1 (cascade, cross_mesh): RX(p_w) RX(a_w) = RX(a_w + p_w)
+  int n_diag_runs;  // n <= 5: runs of >= 2 consecutive diagonal gates (RZ / CRZ); each owns a 2^n phase table behind
+                    // the per-gate entries of the trig buffer (see qc_fill_diag_tables)
 };
 
 // Channel numbering of the derivative ("jet") channels carried through the network:
@@ -52,6 +54,55 @@ struct qc_program {
 static inline int qc_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------ wave-level reductions
+// ---- fused diagonal runs (register family, n <= 5)
+// A run of >= 2 consecutive RZ / CRZ gates is one element-wise multiply by D[k] = prod_g phase_g(k), phase =
+// c -+ i s by the target bit (CRZ: only where the control bit is set).  The tables live behind the n_gates per-gate
+// entries of the trig buffer ({c, s} = {Re D, Im D}), run r at [n_gates + r * 2^n, ...), and are rebuilt with it.
+__host__ __device__ inline bool qc_is_diag_op(int op) { return op == 2 /* QC_RZ */ || op == 6 /* QC_CRZ */; }
+
+inline int qc_count_diag_runs(const QcGate* gates, int n_gates, int n_qubits) {
+  if (n_qubits > 5) return 0;
+  int runs = 0;
+  for (int g = 0; g < n_gates;) {
+    if (!qc_is_diag_op(gates[g].op)) { ++g; continue; }
+    int e = g;
+    while (e < n_gates && qc_is_diag_op(gates[e].op)) ++e;
+    if (e - g >= 2) ++runs;
+    g = e;
+  }
+  return runs;
+}
+
+// one thread per amplitude k (tid < 2^n) after the per-gate entries of `trig` are complete and block-visible
+__device__ inline void qc_fill_diag_tables(const QcGate* __restrict__ prog, int n_gates, int n_qubits,
+                                           QcTrig* __restrict__ trig, int tid) {
+  if (n_qubits > 5 || tid >= (1 << n_qubits)) return;
+  const int k = tid;
+  int r = 0;
+  for (int g = 0; g < n_gates;) {
+    if (!qc_is_diag_op(prog[g].op)) { ++g; continue; }
+    int e = g;
+    while (e < n_gates && qc_is_diag_op(prog[e].op)) ++e;
+    if (e - g >= 2) {
+      float dr = 1.f, di = 0.f;
+      for (int h = g; h < e; ++h) {
+        const QcGate gt = prog[h];
+        const bool ctl = gt.op == 6;
+        const int tb = ctl ? gt.bb : gt.ba;
+        if (ctl && !((k >> gt.ba) & 1)) continue;
+        const float c = trig[h].c, s = ((k >> tb) & 1) ? trig[h].s : -trig[h].s;
+        const float nr = dr * c - di * s, ni = dr * s + di * c;
+        dr = nr;
+        di = ni;
+      }
+      QcTrig t = {dr, di, 0.f, 0.f};
+      trig[n_gates + r * (1 << n_qubits) + k] = t;
+      ++r;
+    }
+    g = e;
+  }
+}
+
 // Sum over the 64 lanes of a wave with DPP row operations (no LDS traffic).  The total is
 // valid in lane 63 (and only there).
 __device__ __forceinline__ float qc_wave_sum_to_lane63(float v) {

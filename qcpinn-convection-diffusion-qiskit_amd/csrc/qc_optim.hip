@@ -59,7 +59,7 @@ struct QcAdamArgs {
   float* hist;
   int hist_cap;
   const QcGate* prog;
-  int n_gates, theta_off;
+  int n_gates, theta_off, n_qubits;
   QcTrig* trig;
 };
 
@@ -96,7 +96,7 @@ __device__ __forceinline__ void adam_block(const QcAdamArgs& a, float* s_red) {
     prm[i] -= step_size * (mi / denom);
   }
   __syncthreads();
-  if (prog != nullptr)
+  if (prog != nullptr) {
     for (int g = threadIdx.x; g < n_gates; g += blockDim.x) {
       const QcGate gt = prog[g];
       QcTrig tr = {1.f, 0.f, 0.f, 0.f};
@@ -106,6 +106,9 @@ __device__ __forceinline__ void adam_block(const QcAdamArgs& a, float* s_red) {
       }
       trig[g] = tr;
     }
+    __syncthreads();
+    qc_fill_diag_tables(prog, n_gates, a.n_qubits, trig, threadIdx.x);
+  }
   if (threadIdx.x == 0) {
     const float lr_ = flat[NP], lb = flat[NP + 1], li = flat[NP + 2];
     const float loss = hp.w_res * lr_ + hp.w_bc * lb + hp.w_ic * li;
@@ -262,6 +265,10 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
       }
       a.trig[gi] = tr;
     }
+  if (a.prog != nullptr) {
+    __syncthreads();
+    qc_fill_diag_tables(a.prog, a.n_gates, a.n_qubits, a.trig, tid);
+  }
   if (tid == 0) {
     const float lr_ = s_loss[0], lb = s_loss[1], li = s_loss[2];
     const float loss = hp.w_res * lr_ + hp.w_bc * lb + hp.w_ic * li;
@@ -294,17 +301,20 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
   }
 }
 
-__global__ void k_prep_trig(const QcGate* __restrict__ prog, int n_gates, const float* __restrict__ theta,
-                            QcTrig* __restrict__ trig) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_gates) return;
-  const QcGate gt = prog[g];
-  QcTrig tr = {1.f, 0.f, 0.f, 0.f};
-  if (gt.op != QC_U4 && gt.slot >= 0) {
-    tr.th = theta[gt.slot];
-    sincosf(0.5f * tr.th, &tr.s, &tr.c);
+// one block: per-gate (cos, sin, theta) entries, then the phase tables of the fused diagonal runs
+__global__ void __launch_bounds__(256) k_prep_trig(const QcGate* __restrict__ prog, int n_gates, int n_qubits,
+                                                   const float* __restrict__ theta, QcTrig* __restrict__ trig) {
+  for (int g = threadIdx.x; g < n_gates; g += 256) {
+    const QcGate gt = prog[g];
+    QcTrig tr = {1.f, 0.f, 0.f, 0.f};
+    if (gt.op != QC_U4 && gt.slot >= 0) {
+      tr.th = theta[gt.slot];
+      sincosf(0.5f * tr.th, &tr.s, &tr.c);
+    }
+    trig[g] = tr;
   }
-  trig[g] = tr;
+  __syncthreads();
+  qc_fill_diag_tables(prog, n_gates, n_qubits, trig, threadIdx.x);
 }
 
 }  // namespace
@@ -319,6 +329,7 @@ static QcAdamArgs adam_args(float* flat, int NP, float* prm, float* m, float* v,
   QcAdamArgs a;
   a.flat = flat; a.NP = NP; a.prm = prm; a.m = m; a.v = v; a.st = state; a.hp = hp; a.hist = hist; a.hist_cap = hist_cap;
   a.prog = pg ? pg->d_gates : nullptr; a.n_gates = pg ? pg->n_gates : 0; a.theta_off = theta_off; a.trig = trig;
+  a.n_qubits = pg ? pg->n_qubits : 0;
   return a;
 }
 
@@ -356,7 +367,6 @@ int qc_opt_adam_fold(const float* part, int64_t stride, int RS, float* flat, int
 }
 
 int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t st) {
-  hipLaunchKernelGGL(k_prep_trig, dim3(qc_ceil_div(pg->n_gates, 256)), dim3(256), 0, st, pg->d_gates,
-                     pg->n_gates, theta, trig);
+  hipLaunchKernelGGL(k_prep_trig, dim3(1), dim3(256), 0, st, pg->d_gates, pg->n_gates, pg->n_qubits, theta, trig);
   return QC_OK;
 }
