@@ -120,7 +120,7 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
                  : ((n_qubits >= 6 && n_qubits <= 8) ? qc_wave_match_static(p) : -1);
   p->hbm_plan = nullptr;
   p->amplitude = 0;
-  p->n_diag_runs = qc_count_diag_runs(h, n_gates, n_qubits);
+  qc_find_diag_runs(p);
   p->lead_rx = n_gates >= n_qubits ? 1 : 0;   // RX(p_w) right after the embedding RX(a_w), wire by wire, distinct slots
   for (int g = 0; g < n_qubits && p->lead_rx; ++g)
     if (h[g].op != QC_RX || h[g].ba != n_qubits - 1 - g || h[g].slot < 0) p->lead_rx = 0;

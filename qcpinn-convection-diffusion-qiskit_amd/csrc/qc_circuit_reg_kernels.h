@@ -130,6 +130,7 @@ struct StatProg {
     }
     return r;
   }
+  static_assert(run_ordinal(SP::G) <= QC_MAX_DIAG_RUNS, "more fused diagonal runs than the host records (qc_find_diag_runs)");
   template <int I, bool ADJ, int K>
   __device__ static __forceinline__ void apply_table(SV<N> (&v)[K], const QcTrig* __restrict__ trig) {
     const QcTrig* tab = trig + SP::G + run_ordinal(I) * (1 << N);

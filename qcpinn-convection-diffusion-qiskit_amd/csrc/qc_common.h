@@ -30,6 +30,8 @@ struct QcTrig {
   float pad;
 };
 
+#define QC_MAX_DIAG_RUNS 8
+
 struct qc_program {
   int n_qubits;
   int n_gates;
@@ -43,6 +45,7 @@ struct qc_program {
   int lead_rx;      // 1: gates 0..n-1 are RX on wires 0..n-1 (cascade, cross_mesh): RX(p_w) RX(a_w) = RX(a_w + p_w)
   int n_diag_runs;  // n <= 5: runs of >= 2 consecutive diagonal gates (RZ / CRZ); each owns a 2^n phase table behind
                     // the per-gate entries of the trig buffer (see qc_fill_diag_tables)
+  int diag_g0[QC_MAX_DIAG_RUNS], diag_g1[QC_MAX_DIAG_RUNS];   // gate ranges [g0, g1) of those runs
 };
 
 // Channel numbering of the derivative ("jet") channels carried through the network:
@@ -60,46 +63,60 @@ static inline int qc_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) /
 // entries of the trig buffer ({c, s} = {Re D, Im D}), run r at [n_gates + r * 2^n, ...), and are rebuilt with it.
 __host__ __device__ inline bool qc_is_diag_op(int op) { return op == 2 /* QC_RZ */ || op == 6 /* QC_CRZ */; }
 
-inline int qc_count_diag_runs(const QcGate* gates, int n_gates, int n_qubits) {
-  if (n_qubits > 5) return 0;
-  int runs = 0;
-  for (int g = 0; g < n_gates;) {
-    if (!qc_is_diag_op(gates[g].op)) { ++g; continue; }
-    int e = g;
-    while (e < n_gates && qc_is_diag_op(gates[e].op)) ++e;
-    if (e - g >= 2) ++runs;
-    g = e;
-  }
-  return runs;
-}
+struct QcDiagRuns {   // kernel-argument copy of qc_program's run list
+  int n;
+  int g0[QC_MAX_DIAG_RUNS], g1[QC_MAX_DIAG_RUNS];
+};
 
-// one thread per amplitude k (tid < 2^n) after the per-gate entries of `trig` are complete and block-visible
-__device__ inline void qc_fill_diag_tables(const QcGate* __restrict__ prog, int n_gates, int n_qubits,
-                                           QcTrig* __restrict__ trig, int tid) {
-  if (n_qubits > 5 || tid >= (1 << n_qubits)) return;
-  const int k = tid;
-  int r = 0;
-  for (int g = 0; g < n_gates;) {
-    if (!qc_is_diag_op(prog[g].op)) { ++g; continue; }
+// fills pg->n_diag_runs / diag_g0 / diag_g1 (host); more than QC_MAX_DIAG_RUNS runs: none is fused
+inline void qc_find_diag_runs(qc_program* pg) {
+  pg->n_diag_runs = 0;
+  if (pg->n_qubits > 5) return;
+  for (int g = 0; g < pg->n_gates;) {
+    if (!qc_is_diag_op(pg->h_gates[g].op)) { ++g; continue; }
     int e = g;
-    while (e < n_gates && qc_is_diag_op(prog[e].op)) ++e;
+    while (e < pg->n_gates && qc_is_diag_op(pg->h_gates[e].op)) ++e;
     if (e - g >= 2) {
-      float dr = 1.f, di = 0.f;
-      for (int h = g; h < e; ++h) {
-        const QcGate gt = prog[h];
-        const bool ctl = gt.op == 6;
-        const int tb = ctl ? gt.bb : gt.ba;
-        if (ctl && !((k >> gt.ba) & 1)) continue;
-        const float c = trig[h].c, s = ((k >> tb) & 1) ? trig[h].s : -trig[h].s;
-        const float nr = dr * c - di * s, ni = dr * s + di * c;
-        dr = nr;
-        di = ni;
-      }
-      QcTrig t = {dr, di, 0.f, 0.f};
-      trig[n_gates + r * (1 << n_qubits) + k] = t;
-      ++r;
+      if (pg->n_diag_runs == QC_MAX_DIAG_RUNS) { pg->n_diag_runs = 0; return; }
+      pg->diag_g0[pg->n_diag_runs] = g;
+      pg->diag_g1[pg->n_diag_runs] = e;
+      ++pg->n_diag_runs;
     }
     g = e;
+  }
+}
+inline QcDiagRuns qc_diag_runs_of(const qc_program* pg) {
+  QcDiagRuns r;
+  r.n = pg ? pg->n_diag_runs : 0;
+  for (int i = 0; i < QC_MAX_DIAG_RUNS; ++i) {
+    r.g0[i] = (pg && i < r.n) ? pg->diag_g0[i] : 0;
+    r.g1[i] = (pg && i < r.n) ? pg->diag_g1[i] : 0;
+  }
+  return r;
+}
+
+// one thread per amplitude k (tid < 2^n) after the per-gate entries of `trig` are complete and block-visible.
+// (`cs`: optional LDS copy [n_gates][2] of the (cos, sin) pairs; else read back from `trig`)
+__device__ inline void qc_fill_diag_tables(const QcGate* __restrict__ prog, int n_gates, int n_qubits,
+                                           QcTrig* __restrict__ trig, int tid, const QcDiagRuns& runs,
+                                           const float* cs = nullptr) {
+  if (n_qubits > 5 || tid >= (1 << n_qubits)) return;
+  const int k = tid;
+  for (int r = 0; r < runs.n; ++r) {
+    float dr = 1.f, di = 0.f;
+    for (int h = runs.g0[r]; h < runs.g1[r]; ++h) {
+      const QcGate gt = prog[h];
+      const bool ctl = gt.op == 6;
+      const int tb = ctl ? gt.bb : gt.ba;
+      const float c = cs ? cs[2 * h] : trig[h].c, s0 = cs ? cs[2 * h + 1] : trig[h].s;
+      if (ctl && !((k >> gt.ba) & 1)) continue;
+      const float s = ((k >> tb) & 1) ? s0 : -s0;
+      const float nr = dr * c - di * s, ni = dr * s + di * c;
+      dr = nr;
+      di = ni;
+    }
+    QcTrig t = {dr, di, 0.f, 0.f};
+    trig[n_gates + r * (1 << n_qubits) + k] = t;
   }
 }
 

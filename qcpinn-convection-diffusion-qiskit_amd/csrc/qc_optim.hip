@@ -61,6 +61,7 @@ struct QcAdamArgs {
   const QcGate* prog;
   int n_gates, theta_off, n_qubits;
   QcTrig* trig;
+  QcDiagRuns runs;
 };
 
 __device__ __forceinline__ void adam_block(const QcAdamArgs& a, float* s_red) {
@@ -107,7 +108,7 @@ __device__ __forceinline__ void adam_block(const QcAdamArgs& a, float* s_red) {
       trig[g] = tr;
     }
     __syncthreads();
-    qc_fill_diag_tables(prog, n_gates, a.n_qubits, trig, threadIdx.x);
+    qc_fill_diag_tables(prog, n_gates, a.n_qubits, trig, threadIdx.x, a.runs);
   }
   if (threadIdx.x == 0) {
     const float lr_ = flat[NP], lb = flat[NP + 1], li = flat[NP + 2];
@@ -186,7 +187,7 @@ template <bool FOLD>
 __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* __restrict__ part, int64_t stride, int RS) {
   __shared__ float s_red[16];
   __shared__ float s_loss[3];
-  extern __shared__ float s_theta[];   // [n_theta]
+  extern __shared__ float s_theta[];   // [n_theta], then (cos, sin)[n_gates][2]
   const int NP = a.NP, tid = threadIdx.x;
   const QcOptHyper& hp = a.hp;
   const int step = a.st->step + 1;
@@ -236,6 +237,7 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
   const float bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)step));
   const float step_size = (float)((double)lr / bc1);
   const int n_theta = NP - a.theta_off;
+  float* s_cs = s_theta + (a.prog != nullptr ? n_theta : 0);
 #pragma unroll
   for (int k = 0; k < QC_ADAM_K; ++k) {
     const int i = tid + k * 1024;
@@ -264,10 +266,14 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
         sincosf(0.5f * tr.th, &tr.s, &tr.c);
       }
       a.trig[gi] = tr;
+      if (a.n_qubits <= 5) {          // (cos, sin) of every gate also to LDS, for the diagonal-run tables below
+        s_cs[2 * gi] = tr.c;
+        s_cs[2 * gi + 1] = tr.s;
+      }
     }
-  if (a.prog != nullptr) {
+  if (a.prog != nullptr && a.n_qubits <= 5) {
     __syncthreads();
-    qc_fill_diag_tables(a.prog, a.n_gates, a.n_qubits, a.trig, tid);
+    qc_fill_diag_tables(a.prog, a.n_gates, a.n_qubits, a.trig, tid, a.runs, s_cs);
   }
   if (tid == 0) {
     const float lr_ = s_loss[0], lb = s_loss[1], li = s_loss[2];
@@ -303,7 +309,8 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
 
 // one block: per-gate (cos, sin, theta) entries, then the phase tables of the fused diagonal runs
 __global__ void __launch_bounds__(256) k_prep_trig(const QcGate* __restrict__ prog, int n_gates, int n_qubits,
-                                                   const float* __restrict__ theta, QcTrig* __restrict__ trig) {
+                                                   const float* __restrict__ theta, QcTrig* __restrict__ trig,
+                                                   QcDiagRuns runs) {
   for (int g = threadIdx.x; g < n_gates; g += 256) {
     const QcGate gt = prog[g];
     QcTrig tr = {1.f, 0.f, 0.f, 0.f};
@@ -314,7 +321,7 @@ __global__ void __launch_bounds__(256) k_prep_trig(const QcGate* __restrict__ pr
     trig[g] = tr;
   }
   __syncthreads();
-  qc_fill_diag_tables(prog, n_gates, n_qubits, trig, threadIdx.x);
+  qc_fill_diag_tables(prog, n_gates, n_qubits, trig, threadIdx.x, runs);
 }
 
 }  // namespace
@@ -330,6 +337,7 @@ static QcAdamArgs adam_args(float* flat, int NP, float* prm, float* m, float* v,
   a.flat = flat; a.NP = NP; a.prm = prm; a.m = m; a.v = v; a.st = state; a.hp = hp; a.hist = hist; a.hist_cap = hist_cap;
   a.prog = pg ? pg->d_gates : nullptr; a.n_gates = pg ? pg->n_gates : 0; a.theta_off = theta_off; a.trig = trig;
   a.n_qubits = pg ? pg->n_qubits : 0;
+  a.runs = qc_diag_runs_of(pg);
   return a;
 }
 
@@ -339,7 +347,7 @@ int qc_opt_adam(float* flat, int NP, float* prm, float* m, float* v, QcOptState*
                 float* hist, int hist_cap, const qc_program* pg, int theta_off, QcTrig* trig, hipStream_t st) {
   const QcAdamArgs a = adam_args(flat, NP, prm, m, v, state, hp, hist, hist_cap, pg, theta_off, trig);
   if (adam_fast_ok(NP))
-    hipLaunchKernelGGL((k_adam_fast<false>), dim3(1), dim3(1024), sizeof(float) * (pg ? NP - theta_off : 0), st, a,
+    hipLaunchKernelGGL((k_adam_fast<false>), dim3(1), dim3(1024), sizeof(float) * (pg ? NP - theta_off + 2 * pg->n_gates : 0), st, a,
                        (const float*)nullptr, (int64_t)0, 0);
   else
     hipLaunchKernelGGL(k_adam, dim3(1), dim3(1024), 0, st, a);
@@ -358,7 +366,7 @@ int qc_opt_adam_fold(const float* part, int64_t stride, int RS, float* flat, int
                      QcOptState* state, QcOptHyper hp, float* hist, int hist_cap, const qc_program* pg, int theta_off,
                      QcTrig* trig, hipStream_t st) {
   if (adam_fast_ok(NP)) {
-    hipLaunchKernelGGL((k_adam_fast<true>), dim3(1), dim3(1024), sizeof(float) * (pg ? NP - theta_off : 0), st,
+    hipLaunchKernelGGL((k_adam_fast<true>), dim3(1), dim3(1024), sizeof(float) * (pg ? NP - theta_off + 2 * pg->n_gates : 0), st,
                        adam_args(flat, NP, prm, m, v, state, hp, hist, hist_cap, pg, theta_off, trig), part, stride, RS);
     return QC_OK;
   }
@@ -367,6 +375,7 @@ int qc_opt_adam_fold(const float* part, int64_t stride, int RS, float* flat, int
 }
 
 int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t st) {
-  hipLaunchKernelGGL(k_prep_trig, dim3(1), dim3(256), 0, st, pg->d_gates, pg->n_gates, pg->n_qubits, theta, trig);
+  hipLaunchKernelGGL(k_prep_trig, dim3(1), dim3(256), 0, st, pg->d_gates, pg->n_gates, pg->n_qubits, theta, trig,
+                     qc_diag_runs_of(pg));
   return QC_OK;
 }
