@@ -37,6 +37,18 @@ __global__ void __launch_bounds__(1024) k_reduce_rows(const float* __restrict__ 
   }
 }
 
+// beta^step by repeated squaring in double (<= 31 dependent multiplies; the generic pow() costs ~1 us of a one-block
+// kernel's latency chain); agrees with pow() to a few ulp of double, far below the float it is converted to
+__device__ __forceinline__ double qc_ipow(double b, int e) {
+  double r = 1.0;
+  while (e > 0) {
+    if (e & 1) r *= b;
+    b *= b;
+    e >>= 1;
+  }
+  return r;
+}
+
 __device__ __forceinline__ float block_sum_1024(float v, float* s_red) {
   v = qc_wave_sum(v);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -83,8 +95,8 @@ __device__ __forceinline__ void adam_block(const QcAdamArgs& a, float* s_red) {
   const int step = st->step + 1;
   const float lr = st->lr;
   const float b1 = (float)hp.beta1, b2 = (float)hp.beta2;
-  const double bc1 = 1.0 - pow(hp.beta1, (double)step);
-  const float bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)step));
+  const double bc1 = 1.0 - qc_ipow(hp.beta1, step);
+  const float bc2s = (float)sqrt(1.0 - qc_ipow(hp.beta2, step));
   const float step_size = (float)((double)lr / bc1);
   for (int i = threadIdx.x; i < NP; i += blockDim.x) {
     const float g = flat[i] * coef;
@@ -233,8 +245,8 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
   float coef = hp.max_norm / (norm + 1e-6f);
   coef = coef > 1.f ? 1.f : coef;
   const float b1 = (float)hp.beta1, b2 = (float)hp.beta2;
-  const double bc1 = 1.0 - pow(hp.beta1, (double)step);
-  const float bc2s = (float)sqrt(1.0 - pow(hp.beta2, (double)step));
+  const double bc1 = 1.0 - qc_ipow(hp.beta1, step);
+  const float bc2s = (float)sqrt(1.0 - qc_ipow(hp.beta2, step));
   const float step_size = (float)((double)lr / bc1);
   const int n_theta = NP - a.theta_off;
   float* s_cs = s_theta + (a.prog != nullptr ? n_theta : 0);
