@@ -241,14 +241,27 @@ struct StatProg {
   }
 };
 
+// half-angle (cos, sin) of wire w's embedding rotation for one point
+__device__ __forceinline__ void qc_wire_sincos(float& c, float& s, const float* __restrict__ a, int64_t B, int64_t p, int w,
+                                               const QcTrig* __restrict__ trig, int absorb) {
+  // absorb: gate w is RX(theta_w) on wire w, applied right after RX(a_w): one rotation by a_w + theta_w
+  const float h = 0.5f * (a[(int64_t)w * B + p] + (absorb ? trig[w].th : 0.f));
+  sincosf(h, &s, &c);
+}
+// `cs` != nullptr: the block already holds them in LDS as [cos | sin][N][64] (each of the jet kernels' six waves
+// needs the same 2N values for its 64 points: waves 0..N-1 compute one wire each instead of all six computing all)
 template <int N>
 __device__ __forceinline__ void load_sincos(float (&ca)[N], float (&sa)[N], const float* __restrict__ a,
-                                            int64_t B, int64_t p, const QcTrig* __restrict__ trig, int absorb) {
+                                            int64_t B, int64_t p, const QcTrig* __restrict__ trig, int absorb,
+                                            const float* cs = nullptr) {
 #pragma unroll
   for (int w = 0; w < N; ++w) {
-    // absorb: gate w is RX(theta_w) on wire w, applied right after RX(a_w): one rotation by a_w + theta_w
-    const float h = 0.5f * (a[(int64_t)w * B + p] + (absorb ? trig[w].th : 0.f));
-    sincosf(h, &sa[w], &ca[w]);
+    if (cs != nullptr) {
+      ca[w] = cs[w * 64 + (threadIdx.x & 63)];
+      sa[w] = cs[(N + w) * 64 + (threadIdx.x & 63)];
+    } else {
+      qc_wire_sincos(ca[w], sa[w], a, B, p, w, trig, absorb);
+    }
   }
 }
 
@@ -257,9 +270,9 @@ __device__ __forceinline__ void load_sincos(float (&ca)[N], float (&sa)[N], cons
 template <int N>
 __device__ __forceinline__ void channel_series(float (&P0)[1 << N], float (&P1)[1 << N], float (&P2)[1 << N],
                                                int ch, const float* __restrict__ ajets, int64_t B, int64_t pc,
-                                               const QcTrig* __restrict__ trig, int absorb) {
+                                               const QcTrig* __restrict__ trig, int absorb, const float* cs = nullptr) {
   float ca[N], sa[N], da[N], dda[N];
-  load_sincos<N>(ca, sa, ajets, B, pc, trig, absorb);
+  load_sincos<N>(ca, sa, ajets, B, pc, trig, absorb, cs);
   const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);  // channel holding the first derivative
 #pragma unroll
   for (int w = 0; w < N; ++w) {
@@ -275,7 +288,8 @@ __device__ __forceinline__ void channel_series(float (&P0)[1 << N], float (&P1)[
 // (normalised, zero-padded) initial amplitudes themselves (qc_amp.hip): amplitude k = feature k, real.
 template <int N>
 __device__ __forceinline__ void build_channel(SV<N>& v, int ch, const float* __restrict__ ajets, int64_t B,
-                                              int64_t pc, int amp, const QcTrig* __restrict__ trig, int absorb) {
+                                              int64_t pc, int amp, const QcTrig* __restrict__ trig, int absorb,
+                                              const float* cs = nullptr) {
   if (amp) {
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
@@ -285,7 +299,7 @@ __device__ __forceinline__ void build_channel(SV<N>& v, int ch, const float* __r
     return;
   }
   float P0[1 << N], P1[1 << N], P2[1 << N];
-  channel_series<N>(P0, P1, P2, ch, ajets, B, pc, trig, absorb);
+  channel_series<N>(P0, P1, P2, ch, ajets, B, pc, trig, absorb, cs);
   if (ch == 0) qc_phase_load<N>(v, P0);
   else if (ch <= 3) qc_phase_load<N>(v, P1);
   else qc_phase_load<N>(v, P2);
@@ -420,8 +434,13 @@ __device__ __forceinline__ void k_jets_fwd_body(const int64_t bid, const QcGate*
   const int64_t p = (int64_t)bid * 64 + lane;
   const int64_t pc = p < B ? p : B - 1;
 
+  __shared__ float s_cs[2 * N * 64];         // half-angle cos | sin of the block's 64 points, one wire per wave
+  if (!(amp & 1)) {
+    if (ch < N) qc_wire_sincos(s_cs[ch * 64 + lane], s_cs[(N + ch) * 64 + lane], ajets, B, pc, ch, trig, amp >> 1);
+    __syncthreads();
+  }
   SV<N> v[1];
-  build_channel<N>(v[0], ch, ajets, B, pc, amp & 1, trig, amp >> 1);
+  build_channel<N>(v[0], ch, ajets, B, pc, amp & 1, trig, amp >> 1, s_cs);
   PG::fwd(v, prog, trig, umat, n_gates, amp >> 1);
   if (chi_store != nullptr && p < B) {   // final states for the adjoint kernel of the same step: [6][A2][B]
 #pragma unroll
@@ -494,12 +513,15 @@ __device__ __forceinline__ void k_jets_bwd_body(const int64_t bid, const QcGate*
   float* s_acc = smem + XCH;                 // [6 waves][n_params]
   const int lane = threadIdx.x & 63;
   const int ch = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* s_cs = s_acc + 6 * n_params;        // [cos | sin][N][64] of the embedding half-angles, for the tail
   for (int i = threadIdx.x; i < 6 * n_params; i += 384) s_acc[i] = 0.f;
-  if constexpr (LOAD) __syncthreads();   // (the !LOAD path has its barrier after the state exchange)
-
   const int64_t p = (int64_t)bid * 64 + lane;
   const bool live = p < B;
   const int64_t pc = live ? p : B - 1;
+  if (!(amp & 1) && ch < N)
+    qc_wire_sincos(s_cs[ch * 64 + lane], s_cs[(N + ch) * 64 + lane], ajets, B, pc, ch, trig, amp >> 1);
+  if constexpr (LOAD) __syncthreads();   // (the !LOAD path has its barrier after the state exchange)
+
 
   SV<N> cl[2];
   if constexpr (LOAD) {
@@ -596,7 +618,7 @@ __device__ __forceinline__ void k_jets_bwd_body(const int64_t bid, const QcGate*
     // the embedding (qc_gates.h): un-apply the n embedding rotations on Lambda, then sparse reads
     const float* aj = qc_launder(ajets);
     float ca[N], sa[N], da[N], dda[N];
-    load_sincos<N>(ca, sa, aj, B, pc, trig, amp >> 1);
+    load_sincos<N>(ca, sa, aj, B, pc, trig, amp >> 1, s_cs);
     qc_unembed<N>(cl[1], ca, sa);
     const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);  // channel holding the first derivative
 #pragma unroll
@@ -742,8 +764,8 @@ struct RegLaunch {
   static int jets_bwd(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
                       const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
                       const float* chi_store, hipStream_t st) {
-    const size_t sh = ((size_t)6 * (2u << PG::N) * 64 + (size_t)6 * pg->n_params) * sizeof(float);
-    const size_t sh_load = ((size_t)6 * 3 * PG::N * 64 + (size_t)6 * pg->n_params) * sizeof(float);
+    const size_t sh = ((size_t)6 * (2u << PG::N) * 64 + (size_t)6 * pg->n_params + 2 * PG::N * 64) * sizeof(float);
+    const size_t sh_load = ((size_t)6 * 3 * PG::N * 64 + (size_t)6 * pg->n_params + 2 * PG::N * 64) * sizeof(float);
     if (sh > 160 * 1024) return QC_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
@@ -773,7 +795,7 @@ struct RegLaunch {
                            const float* angles, const float* cot, float* d_angles, int64_t row0_v, int64_t Bv, float* part,
                            int64_t part_stride, hipStream_t st) {
     const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 384);
-    const size_t sh = ((size_t)6 * 3 * PG::N * 64 + (size_t)6 * pg->n_params) * sizeof(float);   // >= the value blocks' 6 rows
+    const size_t sh = ((size_t)6 * 3 * PG::N * 64 + (size_t)6 * pg->n_params + 2 * PG::N * 64) * sizeof(float);   // >= the value blocks' 6 rows
     hipLaunchKernelGGL(k_circ_bwd_both<PG>, dim3(nr + nv), dim3(384), sh, st, pg->d_gates, trig, umat, pg->n_gates,
                        pg->n_params, ajets, qbar, abar, row0_r, Br, chi_store, angles, cot, d_angles, row0_v, Bv, part,
                        part_stride, qc_embed_flags(pg), nv);
