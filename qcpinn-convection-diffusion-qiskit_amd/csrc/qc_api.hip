@@ -211,6 +211,7 @@ static size_t step_circuit_bytes(const qc_program* p, int64_t B_res) {
   // adjoint pass of the step starts from the forward pass's final states instead of recomputing them
   if (use_hbm(p->n_qubits)) return hbm_base_bytes(p) + qc_hbm_keep_bytes(p, B_res);
   if (use_reg(p->n_qubits)) return qc_reg_chi_store_bytes(p, B_res);   // optional: enables the no-recompute adjoint
+  if (use_wave(p->n_qubits)) return qc_wave_chi_store_bytes(p, B_res);   // same, compile-time programs at n = 6..8
   return 0;
 }
 static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -268,7 +269,7 @@ int qc_forward_jets(const qc_program* p, const void* trig, const float* umat, co
   }
   rc = use_reg(p->n_qubits)
            ? qc_reg_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, nullptr, (hipStream_t)stream)
-           : qc_wave_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, (hipStream_t)stream);
+           : qc_wave_jets_fwd(p, (const QcTrig*)trig, umat, ajets, qjets, B, nullptr, (hipStream_t)stream);
   return rc ? rc : after_launch();
 }
 
@@ -286,7 +287,7 @@ int qc_backward_jets(const qc_program* p, const void* trig, const float* umat, c
   rc = use_reg(p->n_qubits)
            ? qc_reg_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, nullptr,
                              (hipStream_t)stream)
-           : qc_wave_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B,
+           : qc_wave_jets_bwd(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, nullptr,
                               (hipStream_t)stream);
   return rc ? rc : after_launch();
 }
@@ -517,6 +518,11 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       // register family: keep the final states of the forward pass for the adjoint kernel of this step
       float* chi_store = (use_reg(n) && cws && cws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res)) ? (float*)cws : nullptr;
       // HBM family: per-tile kept-state store behind the per-tile scratch (present iff the caller's workspace has room)
+      // lanes-as-amplitudes family, compile-time program: final states of the forward kernel kept for the adjoint kernel
+      float* wave_store = nullptr;
+      if (!use_reg(n) && use_wave(n) && cws && qc_wave_chi_store_bytes(d->prog, d->B_res) > 0 &&
+          cws_bytes >= qc_wave_chi_store_bytes(d->prog, d->B_res))
+        wave_store = (float*)cws;
       void* hbm_store = nullptr;
       if (use_hbm(n) && cws && qc_hbm_keep_bytes(d->prog, d->B_res) > 0 &&
           cws_bytes >= hbm_base_bytes(d->prog) + qc_hbm_keep_bytes(d->prog, d->B_res))
@@ -527,6 +533,9 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (use_reg(n)) {
         if ((rc = qc_reg_jets_fwd(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, chi_store, st)))
           return rc;
+        if ((rc = after_launch())) return rc;
+      } else if (wave_store) {
+        if ((rc = qc_wave_jets_fwd(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, wave_store, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if (hbm_store) {
         if ((rc = qc_hbm_forward_keep(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, cws, hbm_base_bytes(d->prog),
@@ -541,6 +550,10 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (use_reg(n)) {
         if ((rc = qc_reg_jets_bwd(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res,
                                   d->part_dev + L.oTh, d->part_stride, 0, d->B_res, chi_store, st))) return rc;
+        if ((rc = after_launch())) return rc;
+      } else if (wave_store) {
+        if ((rc = qc_wave_jets_bwd(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,
+                                   d->part_stride, 0, d->B_res, wave_store, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if (hbm_store) {
         if ((rc = qc_hbm_backward_kept(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,

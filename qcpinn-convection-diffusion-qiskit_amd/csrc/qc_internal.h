@@ -89,9 +89,11 @@ int qc_wave_value_fwd(const qc_program*, const QcTrig*, const float* umat, const
 int qc_wave_value_bwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, const float* cot,
                       float* d_angles, float* part, int64_t part_stride, int64_t row0, int64_t B, hipStream_t);
 int qc_wave_jets_fwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, float* qjets,
-                     int64_t B, hipStream_t);
+                     int64_t B, float* chi_store, hipStream_t);
 int qc_wave_jets_bwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, const float* qbar,
-                     float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, hipStream_t);
+                     float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, const float* chi_store,
+                     hipStream_t);
+size_t qc_wave_chi_store_bytes(const qc_program* pg, int64_t B);
 int qc_mlp_pre_fwd(const float* X, const float* prm, QcLayout L, float* ajets, int64_t B, int nch, hipStream_t);
 int qc_mlp_pre_bwd(const float* X, const float* prm, QcLayout L, const float* abar, float* part,
                    int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t);
