@@ -285,6 +285,72 @@ __global__ void __launch_bounds__(256) k_hbm_expval(const Cplx* __restrict__ chi
   }
 }
 
+// ---- the same sums with the amplitude range of one (channel, point) vector split over QC_XCH blocks (the one-block
+// form above walks 2^n amplitudes with one wave per SIMD: 0.24 ms per tile at n = 16).  Index bits of an amplitude
+// k = chunk * APB + j * 256 + tid: bits [0,8) = thread, [8, 8 + log2(APB/256)) = loop index j, the rest = chunk: only
+// the j bits need a per-amplitude conditional add, thread and chunk bits sign whole partial sums.
+constexpr int QC_XCH = 8;
+template <int NCH>
+__global__ void __launch_bounds__(256) k_hbm_expval_chunk(const Cplx* __restrict__ chi, int T, int n,
+                                                          float* __restrict__ xpart, int chunks) {
+  __shared__ float s_red[4][24];
+  const int c = blockIdx.x / T, t = blockIdx.x % T, chunk = blockIdx.y;
+  const int64_t N = (int64_t)1 << n;
+  const int64_t apb = N / chunks;                       // amplitudes per block (a power of two >= 256)
+  const int jbits = 31 - __clz((int)(apb >> 8));         // log2(apb / 256)
+  const Cplx* x0 = chi + ((size_t)0 * T + t) * N + chunk * apb;
+  const Cplx* xc = chi + ((size_t)c * T + t) * N + chunk * apb;
+  const Cplx* xk = (NCH == 6 && c >= 4) ? chi + ((size_t)(c - 2) * T + t) * N + chunk * apb : nullptr;
+  float tot = 0.f, sj[8];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) sj[b] = 0.f;
+  for (int j = 0; j < (int)(apb >> 8); ++j) {
+    const int64_t k = (int64_t)j * 256 + threadIdx.x;
+    const Cplx a = x0[k];
+    float wgt;
+    if (c == 0) {
+      wgt = a.re * a.re + a.im * a.im;
+    } else {
+      const Cplx b = xc[k];
+      wgt = 2.f * (a.re * b.re + a.im * b.im);
+      if (xk != nullptr) {
+        const Cplx d = xk[k];
+        wgt += 2.f * (d.re * d.re + d.im * d.im);
+      }
+    }
+    tot += wgt;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      if (b < jbits && ((j >> b) & 1)) sj[b] += wgt;
+  }
+  // per index bit: signed sum = (sum over bit clear) - (sum over bit set)
+  float v[24];
+  for (int b = 0; b < n; ++b) {
+    float mine;
+    if (b < 8) mine = ((threadIdx.x >> b) & 1) ? -tot : tot;                 // thread bit
+    else if (b < 8 + jbits) mine = tot - 2.f * sj[b - 8];                    // loop bit
+    else mine = ((chunk >> (b - 8 - jbits)) & 1) ? -tot : tot;               // chunk bit
+    v[b] = qc_wave_sum(mine);
+  }
+  for (int b = 0; b < n; ++b)
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][b] = v[b];
+  __syncthreads();
+  if (threadIdx.x < n) {
+    const int b = threadIdx.x;
+    xpart[(((size_t)c * T + t) * chunks + chunk) * 24 + b] = (s_red[0][b] + s_red[1][b]) + (s_red[2][b] + s_red[3][b]);
+  }
+}
+// qjets[c][w][p0 + t] = sum of the chunks' partials of index bit n-1-w, in order
+__global__ void __launch_bounds__(256) k_hbm_expval_fold(const float* __restrict__ xpart, int nvec, int T, int n, int chunks,
+                                                         int64_t B, int64_t p0, float* __restrict__ qjets) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvec * n) return;
+  const int vec = i / n, w = i % n, c = vec / T, t = vec % T;
+  float sum = 0.f;
+  for (int q = 0; q < chunks; ++q) sum += xpart[((size_t)vec * chunks + q) * 24 + (n - 1 - w)];
+  qjets[((int64_t)c * n + w) * B + p0 + t] = sum;
+}
+
 // ---------------------------------------------------------------- cotangents of the final states
 template <int NCH>
 __global__ void __launch_bounds__(256) k_hbm_lambda(const Cplx* __restrict__ chi, Cplx* __restrict__ lam, int T, int n,
@@ -675,6 +741,7 @@ struct Ws {
   Cplx* tabs;    // [n_tables][N]
   float* wpart;  // [W_GROUPS][N]
   float* gpart;  // [max_param_lgates][nvec * tiles]
+  float* xpart;  // [nch * 64][QC_XCH][24] partial <Z> sums of k_hbm_expval_chunk
 };
 
 constexpr int W_GROUPS = 16;
@@ -860,6 +927,7 @@ size_t qc_hbm_workspace_bytes(const qc_program* pg, int nch, bool backward) {
   }
   b += align_up(sizeof(Cplx) * (size_t)(plan ? plan->n_tables : 0) * N + 256);          // diagonal tables
   b += align_up(sizeof(float) * T * pg->n_qubits * 8);
+  b += align_up(sizeof(float) * (size_t)nch * T * QC_XCH * 24);                        // expval chunk partials
   return b;
 }
 
@@ -889,7 +957,8 @@ static Ws carve(const qc_program* pg, int nch, bool backward, void* ws) {
     w.gpart = (float*)p; p += align_up(sizeof(float) * (size_t)(plan ? plan->max_param_lgates : 0) * nch * T * tiles + 256);
   }
   w.tabs = (Cplx*)p; p += align_up(sizeof(Cplx) * (size_t)(plan ? plan->n_tables : 0) * N + 256);
-  w.wd = (float*)p;
+  w.wd = (float*)p; p += align_up(sizeof(float) * T * pg->n_qubits * 8);
+  w.xpart = (float*)p;
   return w;
 }
 
@@ -1010,7 +1079,13 @@ static int hbm_run(const qc_program* pg, const QcTrig* trig_dev, const float* um
                            trig_dev, g, (float*)nullptr);
     }
     if (!backward) {
-      hipLaunchKernelGGL((k_hbm_expval<NCH>), dim3(NCH * T), dim3(256), 0, st, w.chi, TA, n, B, p0, qjets);
+      if (N >= 256 * QC_XCH && n <= 19) {   // (the chunk kernel keeps 8 loop-bit accumulators: 2^19 / 8 / 256 = 2^8 iterations)
+        hipLaunchKernelGGL((k_hbm_expval_chunk<NCH>), dim3(NCH * T, QC_XCH), dim3(256), 0, st, w.chi, TA, n, w.xpart, QC_XCH);
+        hipLaunchKernelGGL(k_hbm_expval_fold, dim3(qc_ceil_div(NCH * T * n, 256)), dim3(256), 0, st, w.xpart, NCH * T, T, n,
+                           QC_XCH, B, p0, qjets);
+      } else {
+        hipLaunchKernelGGL((k_hbm_expval<NCH>), dim3(NCH * T), dim3(256), 0, st, w.chi, TA, n, B, p0, qjets);
+      }
       continue;
     }
     hipLaunchKernelGGL((k_hbm_lambda<NCH>), dim3(qc_ceil_div(amps, 256)), dim3(256), 0, st, w.chi, w.lam, TA, n, B, p0, qbar);
