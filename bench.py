@@ -1,22 +1,29 @@
 """Benchmark of the hot path: residual collocation points per second through one FULL loss step
 (sample -> BC/IC forward -> PDE residual -> backward -> clip -> Adam -> scheduler; reference
-trainer/diffusion_train.py:30-49,81-90) on BASELINE.json config 2: 4-qubit cascade ansatz, 1 layer,
-H=50, 65 536 residual points per GPU (+ 2 x 21 845 value points), synthetic uniform batches.
+trainer/diffusion_train.py:30-49,81-90) on the 4-qubit cascade model (1 layer, H=50), synthetic uniform batches.
 
     python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU; weak scaling (per-GPU batch fixed, global batch = N x 65 536); the only
-collective is one all-reduce (RCCL) of the flat [gradient | 3 loss sums] vector per step.
-Prints ONE JSON line on rank 0.  ``roofline`` prices the slowest kernel of the step against the
-fp32 vector/matrix peak (157.3 TFLOP/s: the state is register-resident, HBM is not the bound);
-``cpu_baseline`` times the CPU oracle (a torch complex128 restatement of the reference's
-PennyLane path, kind "port") on a bounded sample on this box's host cores.
+N = 1 is BASELINE.json config 2 (65 536 residual + 2 x 21 845 value points).  N > 1 is config 4's shard size,
+131 072 residual points per GPU (1 048 576 over 8 GPUs), weak scaling; the N = 1 line also reports the step at
+that shard size (``other_configs``) so a scaling curve has its own single-GPU base.  With N > 1 and no
+WORLD_SIZE in the environment the script launches its own ranks (``python -m torch.distributed.run`` as a CHILD
+process, before anything touches the GPU) and relays rank 0's JSON line; under ``torch.distributed.run`` it is
+one rank.  One process per GPU; the only collective is one all-reduce (RCCL) of the flat
+[gradient | 3 loss sums] vector per step.
+
+Prints ONE JSON line on rank 0.  ``roofline`` prices the slowest kernel of the step against the fp32 vector
+peak (157.3 TFLOP/s: the state is register-resident, HBM is not the bound); ``other_configs`` (N = 1) times a
+few full-size steps of BASELINE configs 1, 3, 4-shard and 5; ``cpu_baseline`` times the CPU oracle (a torch
+complex128 restatement of the reference's PennyLane path, kind "port") on a bounded sample on this box's host
+cores.
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,8 +33,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = "qcpinn-convection-diffusion-qiskit_amd"
 
-PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector == fp32 matrix (MFMA f32) peak
+PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector peak (the kernels use no MFMA)
 PEAK_HBM_GBS = 8000.0
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
 def base_args(n=4, layers=1, ansatz="cascade", hidden=50):
@@ -68,7 +76,7 @@ def time_kernels(tr, reps=20):
     on the resident step buffers through its own C-ABI entry point."""
     import ctypes as C
     eng, fs, lib = tr.eng, tr.fs, tr.eng.lib
-    d, c = fs.desc, eng.circuit
+    d = fs.desc
     st = torch.cuda.current_stream(eng.device).cuda_stream
     NPo = eng.theta_off
     rows_res = (fs.B_res + 63) // 64
@@ -125,10 +133,25 @@ def time_kernels(tr, reps=20):
     return out
 
 
+def _cpu_steps(osol, B, budget_s, max_steps):
+    torch.manual_seed(1)
+    m = osol.OracleSolver(base_args(), device=torch.device("cpu"))
+    osol.train_step(m, B)                     # warm-up
+    t0, steps = time.time(), 0
+    while True:
+        osol.train_step(m, B)
+        steps += 1
+        if time.time() - t0 > budget_s or steps >= max_steps:
+            break
+    return steps, time.time() - t0
+
+
 def cpu_baseline(budget_s=24.0):
     """The CPU oracle's full training step (oracle/solver.py: torch complex128 per-gate statevector +
     torch double backward, the algorithm class of the reference's PennyLane default.qubit/backprop
-    path) on this box's host cores, same model, bounded sample: residual batch 4096 (+2x1365).
+    path) on this box's host cores, same model, bounded samples.  ``value`` is the CPU path at its most
+    favourable batch (4 096 residual + 2 x 1 365 value points); ``config1`` is the reference's own
+    configuration (batch 64, and 128 — the effective batch of the stock script, quirk Q1).
     torch's intra-op thread count is picked by a short probe (tiny per-gate tensors scale badly on
     very many threads), and the one used is reported as `cores`."""
     import warnings
@@ -140,42 +163,123 @@ def cpu_baseline(budget_s=24.0):
     best_t, best_dt = cands[0], float("inf")
     for t in cands:
         torch.set_num_threads(t)
-        torch.manual_seed(1)
-        m = osol.OracleSolver(base_args(), device=torch.device("cpu"))
-        osol.train_step(m, B)                     # warm-up
-        t0 = time.time()
-        osol.train_step(m, B)
-        dt = time.time() - t0
+        _, dt = _cpu_steps(osol, B, 0.0, 1)
         if dt < best_dt:
             best_t, best_dt = t, dt
     torch.set_num_threads(best_t)
-    torch.manual_seed(1)
-    m = osol.OracleSolver(base_args(), device=torch.device("cpu"))
-    osol.train_step(m, B)
-    t0, steps = time.time(), 0
-    while True:
-        osol.train_step(m, B)
-        steps += 1
-        if time.time() - t0 > budget_s * 0.6 or steps >= 50:
-            break
-    dt = time.time() - t0
+    steps, dt = _cpu_steps(osol, B, budget_s * 0.5, 50)
+    small = {}
+    torch.set_num_threads(min(8, best_t))       # 16 amplitudes x 64 points: more threads only add overhead
+    for b in (64, 128):
+        s, d = _cpu_steps(osol, b, budget_s * 0.12, 40)
+        small[f"b{b}"] = {"residual_points_per_s": s * b / d, "ms_per_step": d / s * 1e3, "steps": s,
+                          "threads": min(8, best_t)}
     torch.set_num_threads(default_threads)
     return {"value": steps * B / dt, "unit": "residual collocation points/s", "cores": best_t,
-            "kind": "port", "host_cpus": os.cpu_count(),
+            "kind": "port", "host_cpus": os.cpu_count(), "config1": small,
             "sample": f"{steps} full training steps at residual batch {B} (+2x{B // 3} value points), "
                       f"{dt / steps * 1e3:.0f} ms/step, {best_t} torch threads (best of {cands}), "
-                      f"torch {torch.__version__} CPU complex128 oracle"}
+                      f"torch {torch.__version__} CPU complex128 oracle; config1 = the same step at the reference's "
+                      f"own batch 64 / 128"}
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r01_traffic.json:
-    FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md + WRITE_SIZE), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def measured_traffic():
+    """HBM bytes per launch per kernel from the committed rocprofv3 PMC passes of this command (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md), or {}."""
     try:
-        with open(path) as f:
-            return json.load(f).get(kernel)
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def timed_steps(model_args, global_batch, steps, warmup, dev, dist=None):
+    """`steps` full training steps of one configuration on this rank; returns (seconds, trainer, model, host_s)."""
+    Solver = importlib.import_module(PKG + ".nn.DVPDESolver").DVPDESolver
+    trainer = importlib.import_module(PKG + ".trainer.diffusion_train")
+    torch.manual_seed(1)
+    model = Solver(model_args, Log(), device=dev)
+    tr = trainer.FusedTrainer(model, global_batch, capacity=steps + warmup)
+    for _ in range(warmup):
+        tr.sample()
+        tr.step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.sample()
+        tr.step()
+    t_enqueue = time.perf_counter() - t0           # host time to enqueue the K steps (no sync inside a step)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, tr, model, t_enqueue
+
+
+def other_configs(dev):
+    """A few full training steps of the other BASELINE.json configurations on one GPU (they are parity-test cases
+    of tests/, timed here so the driver's record holds them): each with the roofline that bounds it."""
+    H = 50
+    cases = [
+        ("config 1: 4-qubit cascade, batch 64 (the reference's CPU-runnable case)", base_args(), 64, 200, 20),
+        ("config 1 at the stock script's effective batch 128 (quirk Q1)", base_args(), 128, 200, 20),
+        ("config 4 shard: 4-qubit cascade, 131072 residual points on one GPU", base_args(), 131072, 50, 5),
+        ("config 3: 8-qubit layered x2, batch 131072", base_args(8, 2, "layered"), 131072, 5, 2),
+        ("config 5: 16-qubit cross_mesh, batch 8192 (HBM-resident statevectors)", base_args(16, 1, "cross_mesh"), 8192, 3, 1),
+    ]
+    out = []
+    for name, margs, B, steps, warmup in cases:
+        try:
+            dt, tr, model, _ = timed_steps(margs, B, steps, warmup, dev)
+        except Exception as e:          # a failure here must not lose the headline line
+            out.append({"workload": name, "error": f"{type(e).__name__}: {e}"})
+            continue
+        n = margs["num_qubits"]
+        F = model.quantum_layer.program.algorithmic_flops()
+        flops_pt = (13 + 1 / 3) * (F + 2 * (3 * H + H * n) + 2 * (n * H + H))
+        rate = steps * B / dt
+        row = {"workload": name, "ms_per_step": dt / steps * 1e3, "points_per_s": rate, "steps": steps,
+               "final_loss": tr.opt.read()["loss"]}
+        if n >= 9:      # statevectors live in HBM: 13 1/3 channel-evaluations x (one write + one read of 2^n complex64)
+            bytes_pt = (13 + 1 / 3) * 2 * (1 << n) * 8
+            row.update(bound="hbm", roofline_frac=bytes_pt * rate / (PEAK_HBM_GBS * 1e9), achieved=bytes_pt * rate / 1e9,
+                       peak=PEAK_HBM_GBS, unit="GB/s", algorithmic_bytes_per_point=bytes_pt)
+        else:           # register / lane resident statevectors: fp32 vector pipe
+            row.update(bound="valu", roofline_frac=flops_pt * rate / (PEAK_F32_TFLOPS * 1e12), achieved=flops_pt * rate / 1e12,
+                       peak=PEAK_F32_TFLOPS, unit="TFLOP/s", algorithmic_flops_per_point=flops_pt)
+        out.append(row)
+        del tr, model
+        torch.cuda.empty_cache()
+    return out
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child process group (never exec: this
+    process may not be replaced once a GPU runtime is loaded, and it has not touched the GPU yet), relay rank 0's
+    JSON line and the return code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(a.gpus), "--steps", str(a.steps), "--warmup", str(a.warmup)]
+    if a.batch_per_gpu:
+        cmd += ["--batch-per-gpu", str(a.batch_per_gpu)]
+    if a.no_cpu_baseline:
+        cmd += ["--no-cpu-baseline"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return p.returncode if p.returncode != 0 or line is not None else 1
 
 
 def main():
@@ -183,17 +287,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch-per-gpu", type=int, default=65536)
+    ap.add_argument("--batch-per-gpu", type=int, default=0,
+                    help="residual points per GPU (default: 65536 = config 2 at N = 1, 131072 = config 4's shard at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))             # before any GPU call in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        sys.exit(f"--gpus {a.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     dev = torch.device("cuda", local % torch.cuda.device_count())
@@ -210,32 +316,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    Solver = importlib.import_module(PKG + ".nn.DVPDESolver").DVPDESolver
-    trainer = importlib.import_module(PKG + ".trainer.diffusion_train")
+    per_gpu = a.batch_per_gpu or (65536 if world == 1 else 131072)
     args = base_args()
-    torch.manual_seed(1)
-    model = Solver(args, Log(), device=dev)
-    torch.manual_seed(1234 + rank)                 # each rank draws its own shard of the global batch
-    global_batch = a.batch_per_gpu * world
-    tr = trainer.FusedTrainer(model, global_batch, capacity=a.steps + a.warmup)
-
-    def one_step():
-        tr.sample()
-        tr.step()
-
-    for _ in range(a.warmup):
-        one_step()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        one_step()
-    t_enqueue = time.perf_counter() - t0           # host time to enqueue the K steps (no sync inside a step)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    global_batch = per_gpu * world
+    dt, tr, model, t_enqueue = timed_steps(args, global_batch, a.steps, a.warmup, dev, dist)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -252,32 +336,40 @@ def main():
         ach = flops[dom] * tr.B_res / (kt[dom] * 1e-3) / 1e12
         step_ms = dt / a.steps * 1e3
         value = a.steps * global_batch / dt
-        # algorithmic HBM bytes of the step: what must cross HBM per residual point if every stage were
-        # fused (X in: 12 B) vs what the staged pipeline moves (4 jet buffers of 6n floats, written+read)
-        staged_bytes = (2 * 4 * 6 * n * 4 + 2 * 12) * tr.B_res + (2 * 4 * n * 4 + 2 * 12) * (tr.n_ic + tr.n_bc)
+        traffic = measured_traffic() if (world == 1 and per_gpu == 65536) else {}
+        step_bytes = sum(v for k, v in traffic.items() if k.startswith("stage_") or k in ("fold_rows", "adam")) or None
+        cfg_name = ("BASELINE config 2" if (world == 1 and per_gpu == 65536) else
+                    "BASELINE config 4" if global_batch == 1048576 else "BASELINE config 2 model")
         out = {
             "metric": "collocation-points/sec (PDE+BC+IC loss step), 4-qubit cascade",
             "value": value, "unit": "residual collocation points/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: DV solver, 4 qubits, cascade, 1 layer, H=50, "
-                                   f"{a.batch_per_gpu} residual + 2x{a.batch_per_gpu // 3} BC/IC points per GPU",
-                       "global_batch": global_batch, "parallelism": f"dp{world}",
+            "config": {"workload": f"{cfg_name}: DV solver, 4 qubits, cascade, 1 layer, H=50, "
+                                   f"{per_gpu} residual + 2x{per_gpu // 3} BC/IC points per GPU",
+                       "global_batch": global_batch, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
                        "total_points_per_s": a.steps * (global_batch + 2 * (global_batch // 3)) / dt,
                        "final_loss": rec["loss"], "host_enqueue_ms_per_step": t_enqueue / a.steps * 1e3},
-            "roofline": {"bound": "mfma", "pipe": "fp32 VALU (no MFMA used; fp32 vector peak == fp32 MFMA peak)",
+            "roofline": {"bound": "valu", "pipe": "fp32 VALU (register-resident statevectors: no MFMA, no dense contraction)",
                          "kernel": dom, "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": ach / PEAK_F32_TFLOPS, "traffic": measured_traffic(dom),
+                         "frac": ach / PEAK_F32_TFLOPS, "traffic": traffic.get(dom),
+                         "traffic_source": (TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)")
+                         if traffic.get(dom) else None,
                          "kernel_ms": kt[dom], "algorithmic_flops_per_launch": flops[dom] * tr.B_res,
                          "step_frac": flops["step_total"] * value / world / 1e12 / PEAK_F32_TFLOPS,
-                         "hbm_GBps_staged_pipeline": staged_bytes / (step_ms * 1e-3) / 1e9,
-                         "hbm_frac": staged_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                         "hbm_bytes_per_step_measured": step_bytes,
+                         "hbm_GBps_measured": (step_bytes / (step_ms * 1e-3) / 1e9) if step_bytes else None,
+                         "hbm_frac": (step_bytes / (step_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if step_bytes else None},
             "kernels_ms": kt,
         }
+        del tr, model
+        torch.cuda.empty_cache()
+        if world == 1 and not a.no_other_configs:
+            out["other_configs"] = other_configs(dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 1
+#define QC_ABI_VERSION 2
 
 typedef struct qc_program qc_program; /* device-resident gate program (opaque) */
 
@@ -97,7 +97,10 @@ int qc_pre_backward(const float* X_dev, const float* params_dev, int H, int n, i
                     int nch, void* stream);
 
 typedef struct qc_pde {
-  float D, vx, vy;        /* nn/pde.py:53-55 defaults 0.01, 1, 1 */
+  float D, vx, vy;        /* nn/pde.py:53-55 defaults 0.01, 1, 1: the constants of the analytic targets (mode 2) */
+  /* operator coefficients, residual = c_t u_t + c_x u_x + c_y u_y - (d_xx u_xx + d_yy u_yy): with the sigma scalings of
+   * nn/pde.py:60-70 folded in, c_t = 1/sigma_t, c_x = v_x/sigma_x, c_y = v_y/sigma_y, d_xx = D/sigma_x^2, d_yy = D/sigma_y^2 */
+  float c_t, c_x, c_y, d_xx, d_yy;
   float w_res;            /* d loss / d residual scale: 2*weight/N (weight 2, trainer/diffusion_train.py:47) */
   float inv_n_res;        /* 1/N for the logged MSE */
   float w_val_a, w_val_b; /* same for the value segments: a = IC (weight 2), b = BC (weight 4) */
@@ -133,9 +136,11 @@ typedef struct qc_opt_hyper {
   float w_res, w_bc, w_ic;
 } qc_opt_hyper;
 
-/* opt_state_dev: 64-byte record {lr, best, num_bad, step, last_loss, last_norm, loss_parts[3]}.
- * flat_dev = [grad[NP] | L_r, L_bc, L_ic].  Clips, applies Adam, steps the plateau scheduler,
- * appends the loss to hist_dev[step] and refreshes the trig table from the new theta. */
+/* opt_state_dev: 64-byte record {float lr, best; int num_bad, step; float last_loss, last_norm, loss_parts[3];
+ * int hist_base; pad}.  flat_dev = [grad[NP] | L_r, L_bc, L_ic].  Clips, applies Adam, steps the plateau
+ * scheduler, writes the loss of (1-based) step s to hist_dev[s - 1 - hist_base] when that index lies in
+ * [0, hist_cap) (hist_base = steps taken before this history buffer started, e.g. by an earlier train() call on
+ * the same optimiser state) and refreshes the trig table from the new theta. */
 int qc_adam_step(float* flat_dev, int NP, float* params_dev, float* m_dev, float* v_dev, void* opt_state_dev,
                  const qc_opt_hyper* hp, float* hist_dev, int hist_cap, const qc_program* prog, int theta_off,
                  void* trig_dev, void* stream);

@@ -27,7 +27,8 @@ inline QcLayout qc_layout(int H, int n, int n_theta) {
 constexpr int QC_PB_CONVECTION_DIFFUSION = 0, QC_PB_PURE_DIFFUSION = 1;   // == QC_PROBLEM_* of the public header
 
 struct QcPde {  // == qc_pde of the public header
-  float D, vx, vy;
+  float D, vx, vy;                 // physical constants: analytic targets of mode 2
+  float c_t, c_x, c_y, d_xx, d_yy; // operator coefficients (sigma scalings folded in)
   float w_res;
   float inv_n_res;
   float w_val_a, w_val_b;
@@ -45,7 +46,8 @@ struct QcOptState {
   float last_loss;
   float last_norm;
   float loss_parts[3];
-  int pad[7];
+  int hist_base;  // steps taken before this history buffer started: the loss of step s goes to hist[s - 1 - hist_base]
+  int pad[6];
 };
 
 struct QcOptHyper {  // == qc_opt_hyper of the public header

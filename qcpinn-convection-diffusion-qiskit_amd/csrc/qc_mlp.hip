@@ -5,7 +5,8 @@
 // + loss.backward():
 //   pre  : Linear(3,H) -> Tanh -> Linear(H,n)      nn/DVPDESolver.py:37-43
 //   post : Linear(n,H) -> Tanh -> Linear(H,1)      nn/DVPDESolver.py:45-51
-//   residual = u_t + v_x u_x + v_y u_y - D (u_xx + u_yy)          nn/pde.py:53-72
+//   residual = u_t/s_t + v_x u_x/s_x + v_y u_y/s_y - D (u_xx/s_x^2 + u_yy/s_y^2)    nn/pde.py:53-72
+//            = c_t u_t + c_x u_x + c_y u_y - (d_xx u_xx + d_yy u_yy) with the coefficients of QcPde
 //   targets u(t,x,y), r(t,x,y) (incl. the -400 constant)           data/diffusion_dataset.py:20-38
 //   loss parts = MSE(residual, r), MSE(u_bc, u), MSE(u_ic, u)      trainer/diffusion_train.py:44-47
 //
@@ -284,11 +285,11 @@ template <int NCH>
 __device__ __forceinline__ void expand_ub(float (&ub)[NCH], float ub0, float gsc, const QcPde& pde) {
   ub[0] = ub0;
   if constexpr (NCH == 6) {
-    ub[1] = gsc;
-    ub[2] = gsc * pde.vx;
-    ub[3] = gsc * pde.vy;
-    ub[4] = -pde.D * gsc;
-    ub[5] = -pde.D * gsc;
+    ub[1] = gsc * pde.c_t;
+    ub[2] = gsc * pde.c_x;
+    ub[3] = gsc * pde.c_y;
+    ub[4] = -pde.d_xx * gsc;
+    ub[5] = -pde.d_yy * gsc;
   }
 }
 
@@ -375,7 +376,7 @@ __device__ __forceinline__ void k_post_body(const int64_t bid, const float* __re
     __syncthreads();   // s_buf is reused for the qbar partials below
     u[0] += prm[L.ob4];
     float res = 0.f;
-    if constexpr (NCH == 6) res = u[1] + pde.vx * u[2] + pde.vy * u[3] - pde.D * (u[4] + u[5]);
+    if constexpr (NCH == 6) res = pde.c_t * u[1] + pde.c_x * u[2] + pde.c_y * u[3] - (pde.d_xx * u[4] + pde.d_yy * u[5]);
     if constexpr (MODE == 0) {
       if (live && wave == 0) {
         if (out_u) out_u[p] = u[0];

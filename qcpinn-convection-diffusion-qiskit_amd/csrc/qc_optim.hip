@@ -149,7 +149,8 @@ __device__ __forceinline__ void adam_block(const QcAdamArgs& a, float* s_red) {
     st->loss_parts[0] = lr_;
     st->loss_parts[1] = lb;
     st->loss_parts[2] = li;
-    if (hist != nullptr && step - 1 < hist_cap) hist[step - 1] = loss;
+    const int hi = step - 1 - st->hist_base;
+    if (hist != nullptr && hi >= 0 && hi < hist_cap) hist[hi] = loss;
   }
 }
 
@@ -206,6 +207,7 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
   const float lr = a.st->lr;
   float best = a.st->best;
   int bad = a.st->num_bad;
+  const int hist_base = a.st->hist_base;
   float g[QC_ADAM_K], mi[QC_ADAM_K], vi[QC_ADAM_K], pi[QC_ADAM_K];
 #pragma unroll
   for (int k = 0; k < QC_ADAM_K; ++k) {
@@ -312,10 +314,12 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
     o.loss_parts[0] = lr_;
     o.loss_parts[1] = lb;
     o.loss_parts[2] = li;
+    o.hist_base = hist_base;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) o.pad[k] = 0;
+    for (int k = 0; k < 6; ++k) o.pad[k] = 0;
     *a.st = o;
-    if (a.hist != nullptr && step - 1 < a.hist_cap) a.hist[step - 1] = loss;
+    const int hi = step - 1 - hist_base;
+    if (a.hist != nullptr && hi >= 0 && hi < a.hist_cap) a.hist[hi] = loss;
   }
 }
 

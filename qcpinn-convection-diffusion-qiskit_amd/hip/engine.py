@@ -197,13 +197,17 @@ class SolverEngine:
             raise L.QcError(f"flat parameter vector has {flat_params.numel()} entries, layout needs {self.NP}")
         self.flat = _need(flat_params, self.device, "flat params")
         self.D, self.vx, self.vy = float(D), float(vx), float(vy)
+        self.sigma = (1.0, 1.0, 1.0)                           # sigma_t, sigma_x, sigma_y of nn/pde.py:53-70
         self.problem = L.QC_PROBLEM_CONVECTION_DIFFUSION      # analytic targets of the fused loss (qcpinn_hip.h)
         self._fused: Dict[Tuple[int, int, int], "FusedStep"] = {}
 
     # ------------------------------------------------------------------ helpers
     def _pde(self, n_res=1, n_ic=1, n_bc=1, n_seg_a=0) -> L.QcPde:
         # loss = 2*MSE_res + 4*MSE_bc + 2*MSE_ic (trainer/diffusion_train.py:47); d/d(err) = 2*w/N * err
-        return L.QcPde(self.D, self.vx, self.vy, 4.0 / n_res, 1.0 / n_res, 4.0 / n_ic, 8.0 / n_bc,
+        # u_k/sigma_k and u_kk/sigma_k^2 (nn/pde.py:60-70) are scalings of channels the kernels already carry
+        st, sx, sy = self.sigma
+        return L.QcPde(self.D, self.vx, self.vy, 1.0 / st, self.vx / sx, self.vy / sy, self.D / (sx * sx),
+                       self.D / (sy * sy), 4.0 / n_res, 1.0 / n_res, 4.0 / n_ic, 8.0 / n_bc,
                        1.0 / n_ic, 1.0 / n_bc, self.problem, n_seg_a)
 
     def refresh_gates(self) -> None:
@@ -278,7 +282,7 @@ class SolverEngine:
 
     # ------------------------------------------------------------------ fused training step
     def fused(self, B_res: int, n_ic: int, n_bc: int, opt: "OptimState", counts=None) -> "FusedStep":
-        key = (B_res, n_ic, n_bc, id(opt), counts, self.problem, self.D, self.vx, self.vy)
+        key = (B_res, n_ic, n_bc, id(opt), counts, self.problem, self.D, self.vx, self.vy, self.sigma)
         if key not in self._fused:
             self._fused[key] = FusedStep(self, B_res, n_ic, n_bc, opt, counts)
         return self._fused[key]
@@ -306,10 +310,11 @@ class OptimState:
         raw = self.state.cpu().numpy()
         ints = raw.view(np.int32)
         return {"lr": float(raw[0]), "best": float(raw[1]), "num_bad_epochs": int(ints[2]), "step": int(ints[3]),
+                "hist_base": int(ints[9]),
                 "loss": float(raw[4]), "grad_norm": float(raw[5]), "loss_res": float(raw[6]),
                 "loss_bc": float(raw[7]), "loss_ic": float(raw[8])}
 
-    def write(self, lr=None, best=None, num_bad=None, step=None) -> None:
+    def write(self, lr=None, best=None, num_bad=None, step=None, hist_base=None) -> None:
         raw = self.state.cpu().numpy().copy()
         ints = raw.view(np.int32)
         if lr is not None:
@@ -320,11 +325,16 @@ class OptimState:
             ints[2] = num_bad
         if step is not None:
             ints[3] = step
+        if hist_base is not None:
+            ints[9] = hist_base         # the history buffer starts at this (absolute) step count
         self.state.copy_(torch.from_numpy(raw))
 
     def loss_history(self, steps: Optional[int] = None):
-        n = self.read()["step"] if steps is None else steps
-        return self.hist[: min(n, self.hist_cap)].cpu().tolist()
+        """Losses of the first ``steps`` steps of THIS history buffer (default: all taken so far)."""
+        if steps is None:
+            rec = self.read()
+            steps = rec["step"] - rec["hist_base"]
+        return self.hist[: max(0, min(steps, self.hist_cap))].cpu().tolist()
 
 
 class FusedStep:

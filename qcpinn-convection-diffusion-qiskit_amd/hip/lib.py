@@ -37,7 +37,9 @@ class QcError(RuntimeError):
 
 
 class QcPde(C.Structure):
-    _fields_ = [("D", C.c_float), ("vx", C.c_float), ("vy", C.c_float), ("w_res", C.c_float),
+    _fields_ = [("D", C.c_float), ("vx", C.c_float), ("vy", C.c_float),
+                ("c_t", C.c_float), ("c_x", C.c_float), ("c_y", C.c_float), ("d_xx", C.c_float), ("d_yy", C.c_float),
+                ("w_res", C.c_float),
                 ("inv_n_res", C.c_float), ("w_val_a", C.c_float), ("w_val_b", C.c_float),
                 ("inv_n_a", C.c_float), ("inv_n_b", C.c_float), ("problem", C.c_int), ("n_seg_a", C.c_int64)]
 

@@ -51,7 +51,7 @@ class _ResidualFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, solver, pde, *params):
         eng = solver._engine_for(X.device)
-        eng.D, eng.vx, eng.vy = pde
+        eng.D, eng.vx, eng.vy, eng.sigma = pde
         Xc = X.detach().to(torch.float32).contiguous()
         u, res, ajets, qjets = eng.forward(Xc, _engine.NCH)
         ctx.eng, ctx.solver, ctx.pde = eng, solver, pde
@@ -63,7 +63,7 @@ class _ResidualFn(torch.autograd.Function):
     def backward(ctx, gu, gres):
         Xc, ajets, qjets = ctx.saved_tensors
         eng = ctx.eng
-        eng.D, eng.vx, eng.vy = ctx.pde
+        eng.D, eng.vx, eng.vy, eng.sigma = ctx.pde
         eng.refresh_gates()
         d_flat = eng.backward(Xc, ajets, qjets, gu, gres, _engine.NCH)
         return (None, None, None) + ctx.solver._split_flat(d_flat)
@@ -197,13 +197,14 @@ class DVPDESolver(nn.Module):
                 self.logger.print(f"Forward pass failed: {str(e)}")
             raise
 
-    def residual(self, X: torch.Tensor, D=0.01, v_x=1.0, v_y=1.0):
+    def residual(self, X: torch.Tensor, D=0.01, v_x=1.0, v_y=1.0, sigma=(1.0, 1.0, 1.0)):
         """(u, residual) at X (B,3) with the derivative channels carried through the HIP kernels —
         what ``nn.pde.diffusion_operator`` dispatches to for this model."""
         if X.dim() != 2 or X.shape[1] != 3:
             raise ValueError(f"Expected collocation points of shape (B, 3), got {tuple(X.shape)}")
         self._engine_for(X.device)
-        return _ResidualFn.apply(X, self, (float(D), float(v_x), float(v_y)), *_flat_param_list(self))
+        pde = (float(D), float(v_x), float(v_y), tuple(float(s) for s in sigma))
+        return _ResidualFn.apply(X, self, pde, *_flat_param_list(self))
 
     # ------------------------------------------------------------------ checkpoint (same keys as :116-128)
     def save_state(self, path=None):

@@ -29,15 +29,8 @@ def diffusion_operator(model, t, x, y, sigma_t=1.0, sigma_x=1.0, sigma_y=1.0, D=
     y.requires_grad = True
     fused = getattr(model, "residual", None)
     if fused is not None and hasattr(model, "quantum_layer"):
-        # fold the sigma scalings into the coefficients: u_k/s_k and u_kk/s_k^2, whole thing / s_t on u_t
-        if sigma_t != 1.0:
-            raise NotImplementedError("sigma_t != 1 is not supported on the fused HIP path")
-        if sigma_x != sigma_y:
-            raise NotImplementedError("sigma_x != sigma_y is not supported on the fused HIP path")
-        s = float(sigma_x)
-        if s != 1.0:
-            raise NotImplementedError("sigma_x, sigma_y != 1 are not supported on the fused HIP path")
-        return fused(torch.cat((t, x, y), 1), D=D, v_x=v_x, v_y=v_y)
+        # the sigma scalings are folded into the operator coefficients the kernels take (qc_pde.c_*, d_*)
+        return fused(torch.cat((t, x, y), 1), D=D, v_x=v_x, v_y=v_y, sigma=(sigma_t, sigma_x, sigma_y))
     u = model(torch.cat((t, x, y), 1))
     u_t = _grad(u, t) / sigma_t
     u_x = _grad(u, x) / sigma_x

@@ -82,6 +82,7 @@ class FusedTrainer:
             raise _lib.QcError("training a DVPDESolver needs a GPU (HIP kernels, no CPU fallback)")
         self.model, self.device = model, dev
         self.eng = model._engine_for(dev)
+        self.eng.sigma = (1.0, 1.0, 1.0)          # the trainers call the operator with its default scalings
         if pde:
             self.eng.D, self.eng.vx, self.eng.vy = float(pde["D"]), float(pde["vx"]), float(pde["vy"])
             self.eng.problem = int(pde["problem"])
@@ -134,8 +135,8 @@ class FusedTrainer:
                 st.v[off:off + k] = s["exp_avg_sq"].reshape(-1).to(self.device)
                 steps = int(s["step"])
             off += k
-        st.write(best=float(sch.best), num_bad=int(sch.num_bad_epochs), step=steps)
-        self._base_step = steps
+        # a model trained before continues its Adam step count; the loss history of THIS run starts at index 0
+        st.write(best=float(sch.best), num_bad=int(sch.num_bad_epochs), step=steps, hist_base=steps)
         return st
 
     def sync_to_torch(self):

@@ -87,13 +87,14 @@ def make_expvals():
         print("expval", ans, n, L, q.shape)
 
 
-def make_operator(tag, args, B):
+def make_operator(tag, args, B, **op_kw):
+    """``op_kw``: keyword arguments of the reference's diffusion_operator (sigma_t, sigma_x, sigma_y, D, v_x, v_y)."""
     torch.manual_seed(1)
     model = osol.OracleSolver(args)
     g = torch.Generator().manual_seed(11)
     X = torch.rand(B, 3, generator=g)
     t, x, y = X[:, 0:1].clone(), X[:, 1:2].clone(), X[:, 2:3].clone()
-    u, res = ref_pde.diffusion_operator(model, t, x, y)          # the reference's operator
+    u, res = ref_pde.diffusion_operator(model, t, x, y, **op_kw)  # the reference's operator
     # derivative channels, for debugging the jet kernels
     ones = torch.ones_like(u)
     u_t = torch.autograd.grad(u, t, ones, create_graph=True)[0]
@@ -111,7 +112,8 @@ def make_operator(tag, args, B):
              residual=res.detach().numpy(), u_t=u_t.detach().numpy(), u_x=u_x.detach().numpy(),
              u_y=u_y.detach().numpy(), u_xx=u_xx.detach().numpy(), u_yy=u_yy.detach().numpy(),
              angles=a.detach().numpy(), expval=q.detach().numpy(),
-             loss=np.array(loss.item()), grad=flat_grads(model), **state_arrays(model, "w__"))
+             loss=np.array(loss.item()), grad=flat_grads(model), **state_arrays(model, "w__"),
+             **{"op__" + k: np.array(v) for k, v in op_kw.items()})
     print("operator", tag, float(loss))
 
 
@@ -214,6 +216,20 @@ def make_other_operators():
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "operators":
     make_other_operators()
+    sys.exit(0)
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "r2":
+    # round 2: the fused training step of the HBM family (n >= 9: two 64-point tiles with a ragged tail) and of the
+    # lanes-as-amplitudes family on three tiles; diffusion_operator with sigma != 1 (nn/pde.py:53-70)
+    which = sys.argv[2:] or ["hbm", "wave", "sigma"]
+    if "hbm" in which:
+        make_train("cross_mesh_n10_b72", base_args(epochs=3, num_qubits=10, q_ansatz="cross_mesh"), 72)
+    if "wave" in which:
+        make_train("layered_n8_b136", base_args(epochs=3, num_qubits=8, num_quantum_layers=2, q_ansatz="layered"), 136)
+    if "sigma" in which:
+        make_operator("cascade_n4_sigma", base_args(), 48, sigma_t=2.0, sigma_x=0.5, sigma_y=0.5, D=0.02, v_x=0.7, v_y=1.3)
+        make_operator("layered_n8_sigma", base_args(num_qubits=8, num_quantum_layers=2, q_ansatz="layered"), 16,
+                      sigma_t=2.0, sigma_x=0.5, sigma_y=0.5)
     sys.exit(0)
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "n16":

@@ -16,13 +16,13 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qc_version() == 1
+    assert lib.qc_version() == 2
     assert lib.qc_error_string(-1).decode() == "invalid argument"
 
 
 def test_struct_sizes_match_header_layout():
     L = pkg("hip.lib")
-    assert ctypes.sizeof(L.QcPde) == 48
+    assert ctypes.sizeof(L.QcPde) == 72
     assert ctypes.sizeof(L.QcOptHyper) == 56
 
 

@@ -86,3 +86,21 @@ def test_two_rank_allreduce_equals_single_process(tmp_path):
     model.zero_grad()
     loss, l_r, l_bc, l_ic = osol.loss_on_batches(model, X_ic, X_bc, X_res)
     assert abs((2 * whole[-3] + 4 * whole[-2] + 2 * whole[-1]) - loss.item()) < 1e-5
+
+
+def test_bench_self_launch_reaches_its_ranks_without_a_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must spawn its ranks as child processes (not exit with a
+    'use torch.distributed.run' message).  Without a GPU every rank stops at the loud 'needs a GPU' exit, which
+    the launcher relays as a non-zero return code."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("covered by tests/test_gpu_dist.py on a GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode != 0
+    assert "needs a GPU" in p.stdout and "launch N>1 with" not in p.stdout

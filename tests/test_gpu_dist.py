@@ -79,3 +79,25 @@ def test_two_rank_training_matches_reference_history(tmp_path, gpu_device):
     assert not np.array_equal(x0, x1)
     both = np.concatenate([x0, x1])
     assert len(np.unique(both[:, 0])) > 630
+
+
+def test_bench_launches_its_own_ranks(gpu_device):
+    """`python bench.py --gpus 2` with no launcher around it: the script starts its ranks as a child process group
+    and relays rank 0's JSON line.  Rehearsed on this one-GPU box with gloo as the transport (both ranks on
+    cuda:0); on a multi-GPU node the same path runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    env = dict(os.environ, QC_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["per_gpu_batch"] == 131072 and out["config"]["global_batch"] == 262144   # config 4's shard
+    assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
+    assert out["roofline"]["bound"] == "valu" and 0 < out["roofline"]["frac"] < 1

@@ -1,0 +1,132 @@
+"""The fused training step hands the forward pass's final statevectors to the adjoint pass through a per-tile
+store (register family: tile-major chi store; lanes-as-amplitudes family: qc_wave_chi_store_bytes; HBM family:
+one [chi | lam] slot per 64-point tile).  These tests pin that path on MORE THAN ONE tile with a ragged tail:
+
+  * loss history of ``trainer.train`` vs the reference's own ``trainer/diffusion_train.py::train`` driving the CPU
+    oracle (fixtures ``train_cross_mesh_n10_b72`` = HBM family, 2 tiles 64 + 8; ``train_layered_n8_b136`` = wave
+    family, 3 tiles 64 + 64 + 8), 1e-4 on the loss (north_star);
+  * the gradient vector of the kept-state path equals the recompute path's (workspace withheld -> the adjoint
+    kernels recompute the final states) bit for bit;
+  * determinism / batch additivity at BASELINE config 3 and config 5 sizes.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, pkg
+from test_gpu_solver import Log, base_args
+from test_gpu_fullsize import grads_for, make
+
+pytestmark = pytest.mark.gpu
+
+KEPT_CASES = [("cross_mesh_n10_b72", {"epochs": 3, "num_qubits": 10, "q_ansatz": "cross_mesh"}),
+              ("layered_n8_b136", {"epochs": 3, "num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"}),
+              ("cascade_n4_b128", {"epochs": 8})]
+
+
+def _trainer_on_first_batch(tag, over, gpu_device, tmp_path):
+    z = np.load(os.path.join(GOLDEN, f"train_{tag}.npz"))
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    trainer = pkg("trainer.diffusion_train")
+    torch.manual_seed(1)
+    model = Solver(base_args(**over), Log(tmp_path), device=gpu_device)
+    B = int(z["batch_size"])
+    tr = trainer.FusedTrainer(model, B, capacity=4)
+    tr.load_batches(*(torch.from_numpy(z[k][0]) for k in ("X_ic", "X_bc", "X_res")))
+    return z, model, tr
+
+
+@pytest.mark.parametrize("tag,over", KEPT_CASES)
+def test_kept_state_gradient_equals_recompute_gradient(tag, over, gpu_device, tmp_path):
+    """Same batches, same weights: [grad | losses] with the per-tile final-state store vs with the workspace
+    withheld (the adjoint pass recomputes the forward pass's final states).  Both run the same arithmetic on
+    the same inputs in the same order, so the vectors must agree to rounding noise of the recomputation
+    (bit for bit where the forward kernel's stored state is what the adjoint kernel would recompute)."""
+    L = pkg("hip.lib")
+    z, model, tr = _trainer_on_first_batch(tag, over, gpu_device, tmp_path)
+    d = tr.fs.desc
+    n = int(d.n)
+    full_bytes = int(d.circ_ws_bytes)
+    assert full_bytes > 0, "this case must have a kept-state store"
+    tr.fs.run(L.QC_PHASE_GRADS)
+    torch.cuda.synchronize()
+    kept = tr.fs.flat_grad.clone()
+    # reference gradient from the fixture (the reference loop's first backward, before clipping)
+    NP = tr.eng.NP
+    ref = z["grad_raw0"]
+    assert np.abs(kept[:NP].cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    # withhold the store: n >= 9 keeps only the per-tile scratch, n <= 8 gets no workspace at all
+    if n >= 9:
+        base = (int(tr.eng.lib.qc_circuit_workspace_bytes(tr.eng.circuit.handle, 6, 1)) + 255) & ~255
+        assert base < full_bytes
+        d.circ_ws_bytes = base
+    else:
+        d.circ_ws_dev, d.circ_ws_bytes = None, 0
+    tr.fs.run(L.QC_PHASE_GRADS)
+    torch.cuda.synchronize()
+    recomputed = tr.fs.flat_grad.clone()
+    scale = max(1.0, kept.abs().max().item())
+    diff = (kept - recomputed).abs().max().item()
+    assert diff <= 2e-6 * scale, diff
+    if n >= 6:      # same kernels either way (store -> load of the same fp32 values): bit-identical
+        assert torch.equal(kept, recomputed), diff
+
+
+@pytest.mark.parametrize("tag,over", KEPT_CASES[:2])
+def test_multi_tile_train_loop_matches_reference_train(tag, over, gpu_device, tmp_path):
+    z = np.load(os.path.join(GOLDEN, f"train_{tag}.npz"))
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    trainer = pkg("trainer.diffusion_train")
+    torch.manual_seed(1)
+    model = Solver(base_args(**over), Log(tmp_path), device=gpu_device)
+    for name, p in model.named_parameters():
+        assert np.abs(p.detach().cpu().numpy() - z["w0__" + name.replace(".", "__")]).max() == 0.0, name
+    B = int(z["batch_size"])
+    steps = z["X_res"].shape[0]
+    batches = [tuple(torch.from_numpy(z[k][it]) for k in ("X_ic", "X_bc", "X_res")) for it in range(steps)]
+    trainer.train(model, batch_size=B, batches=batches)
+    hist, ref = np.array(model.loss_history), z["loss_history"]
+    assert hist.shape == ref.shape
+    assert np.abs(hist - ref).max() < 1e-4 * max(1.0, np.abs(ref).max()), (hist, ref)
+    diffs = np.concatenate([np.abs(p.detach().cpu().numpy() - z["w1__" + name.replace(".", "__")]).reshape(-1)
+                            for name, p in model.named_parameters()])
+    assert np.median(diffs) < 1e-4 and diffs.max() < 0.25 * 0.005 * steps, (np.median(diffs), diffs.max())
+
+
+def _batches(B, seed):
+    n3 = B // 3
+    g = torch.Generator().manual_seed(seed)
+    X_ic = torch.rand(n3, 3, generator=g) * torch.tensor([0.0, 1.0, 1.0])
+    X_bc = torch.rand(n3, 3, generator=g) * torch.tensor([1.0, 0.0, 1.0])
+    X_res = torch.rand(B, 3, generator=g)
+    return X_ic, X_bc, X_res
+
+
+@pytest.mark.parametrize("over,B,tol", [
+    ({"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"}, 131072, 5e-5),     # BASELINE config 3
+    ({"num_qubits": 16, "q_ansatz": "cross_mesh"}, 8192, 2e-4),                              # BASELINE config 5
+])
+def test_full_size_determinism_and_additivity(over, B, tol, gpu_device):
+    """BASELINE configs 3 and 5 at their full batches (config 5: 128 tiles, a 51.5 GB kept-state store): fixed-order
+    reductions are bit-reproducible, every term of [grad | losses] is a mean over its batch so equal halves
+    recombine by averaging, and the residual and value pipelines add up to the whole step."""
+    X_ic, X_bc, X_res = _batches(B, 9)
+    model = make(gpu_device, **over)
+    f1 = grads_for(model, X_ic, X_bc, X_res)
+    f2 = grads_for(model, X_ic, X_bc, X_res)
+    assert torch.equal(f1, f2)
+    assert torch.isfinite(f1).all()
+    NP = f1.numel() - 3
+    h = B // 2
+    none = X_ic[:0]
+    ra = grads_for(model, none, none, X_res[:h])
+    rb = grads_for(model, none, none, X_res[h:])
+    rfull = grads_for(model, none, none, X_res)
+    scale = max(1.0, rfull.abs().max().item())
+    assert (0.5 * (ra + rb) - rfull).abs().max().item() < tol * scale
+    full_val = grads_for(model, X_ic, X_bc, X_res[:0])
+    scale = max(1.0, f1.abs().max().item())
+    assert (rfull + full_val - f1).abs().max().item() < tol * scale
+    assert f1[NP:].min().item() >= 0.0
