@@ -57,6 +57,17 @@ int qc_prepare_gates(const qc_program* prog, const float* theta_dev, void* trig_
 /* Scratch the circuit entry points need for this program (0 for n <= 8: registers / lanes only;
  * for 9 <= n <= 20 the statevectors of one 64-point tile live in HBM).  nch = 1 or 6. */
 size_t qc_circuit_workspace_bytes(const qc_program* prog, int nch, int backward);
+/* The same for a batch of B points: 9 <= n <= 20 with angle encoding processes every 64-point tile that fits the
+ * workspace in ONE launch per stage, so more scratch than the one-tile minimum above buys fewer, larger launches;
+ * this returns the bytes that keep the whole batch resident (capped by the QC_HBM_KEEP_GB budget, default 96). */
+size_t qc_circuit_workspace_bytes_batch(const qc_program* prog, int nch, int backward, int64_t B);
+/* Execution plan of the HBM-resident family (9 <= n <= 20, angle encoding) for the gate rows of qc_program_create, as
+ * a flat int32 record: stages (local bit sets), rounds (register bit sets), gates and diagonal tables -- the schedule
+ * the kernels run for DVQuantumLayer._quantum_circuit (nn/DVQuantumLayer.py:176-214), which is NOT program order (gates
+ * on disjoint wires and diagonal gates are commuted).  Host-only (no GPU needed).  Returns the number of int32 values
+ * of the record (written up to `cap`), 0 on invalid input.  Layout: csrc/qc_hbm2_plan.h::h2_describe;
+ * tests/test_hbm_plan.py re-executes the record on the CPU against the gate-by-gate program. */
+int qc_hbm_plan_describe(const int32_t* gate_rows, int n_gates, int n_qubits, int n_params, int32_t* out, int cap);
 
 /* ---- DVQuantumLayer.forward, simulator batch branch (nn/DVQuantumLayer.py:151-154):
  * angles [n][B] -> <Z_w> [n][B].  umat_dev: [2 slots][fwd, adjoint][4x4 complex] floats or NULL.

@@ -41,6 +41,20 @@ static inline bool force_wave() {
 static inline bool use_reg(int n) { return n >= 2 && n <= 5 && !force_wave(); }
 static inline bool use_wave(int n) { return n >= 1 && n <= 8; }
 static inline bool use_hbm(int n) { return n >= 9 && n <= 20; }
+// n >= 9, angle encoding: the round-structured plan (qc_circuit_hbm2.hip).  QC_HBM_V1=1 / QC_HBM_SIMPLE=1 keep the
+// round-1 kernels (one LDS round trip per gate / one pass per gate) as cross-checks.
+static inline bool use_h2(const qc_program* p) {
+  static const bool off = [] {
+    const char* a = getenv("QC_HBM_V1");
+    const char* b = getenv("QC_HBM_SIMPLE");
+    return (a && a[0] == '1') || (b && b[0] == '1');
+  }();
+  return p->h2 != nullptr && !p->amplitude && !off;
+}
+static inline double hbm_budget_bytes() {
+  static const double cap_gb = [] { const char* e = getenv("QC_HBM_KEEP_GB"); return e ? atof(e) : 96.0; }();
+  return cap_gb * 1073741824.0;
+}
 
 // A side stream per device so the (small) boundary/initial-value pipeline of a step can overlap the
 // residual pipeline; created once, on first use, never inside a graph capture of the caller.
@@ -84,10 +98,8 @@ const char* qc_error_string(int code) {
 
 int qc_last_hip_error(void) { return g_last_hip; }
 
-int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_params, qc_program** out) {
-  if (!rows || !out || n_gates <= 0 || n_qubits < 1 || n_qubits > 24 || n_params < 0) return QC_ERR_ARG;
-  QcGate* h = (QcGate*)malloc(sizeof(QcGate) * n_gates);
-  if (!h) return QC_ERR_ALLOC;
+// gate rows (opcode, wire_a, wire_b, slot) -> bit-indexed gates; returns false on an invalid row
+static bool parse_rows(const int32_t* rows, int n_gates, int n_qubits, int n_params, QcGate* h, int* n_u4_out) {
   int n_u4 = 0;
   for (int g = 0; g < n_gates; ++g) {
     const int op = rows[4 * g], a = rows[4 * g + 1], b = rows[4 * g + 2], slot = rows[4 * g + 3];
@@ -100,14 +112,38 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
       ok = ok && n_qubits >= 4 && ((slot == 0 && a == 0 && b == 1) || (slot == 1 && a == 2 && b == 3));
       ++n_u4;
     }
-    if (!ok) {
-      free(h);
-      return QC_ERR_ARG;
-    }
+    if (!ok) return false;
     h[g].op = op;
     h[g].ba = n_qubits - 1 - a;
     h[g].bb = two ? n_qubits - 1 - b : -1;
     h[g].slot = (par || op == QC_U4) ? slot : -1;
+  }
+  *n_u4_out = n_u4;
+  return true;
+}
+// RX(p_w) right after the embedding RX(a_w), wire by wire, distinct slots
+static int detect_lead_rx(const QcGate* h, int n_gates, int n_qubits) {
+  if (n_gates < n_qubits) return 0;
+  for (int g = 0; g < n_qubits; ++g)
+    if (h[g].op != QC_RX || h[g].ba != n_qubits - 1 - g || h[g].slot < 0) return 0;
+  for (int g = 0; g < n_qubits; ++g)
+    for (int k = 0; k < g; ++k)
+      if (h[k].slot == h[g].slot) return 0;
+  return 1;
+}
+static bool absorb_enabled() {
+  static const bool no_absorb = [] { const char* e = getenv("QC_NO_ABSORB"); return e && e[0] == '1'; }();
+  return !no_absorb;
+}
+
+int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_params, qc_program** out) {
+  if (!rows || !out || n_gates <= 0 || n_qubits < 1 || n_qubits > 24 || n_params < 0) return QC_ERR_ARG;
+  QcGate* h = (QcGate*)malloc(sizeof(QcGate) * n_gates);
+  if (!h) return QC_ERR_ALLOC;
+  int n_u4 = 0;
+  if (!parse_rows(rows, n_gates, n_qubits, n_params, h, &n_u4)) {
+    free(h);
+    return QC_ERR_ARG;
   }
   qc_program* p = (qc_program*)malloc(sizeof(qc_program));
   if (!p) {
@@ -119,14 +155,10 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p)
                  : ((n_qubits >= 6 && n_qubits <= 8) ? qc_wave_match_static(p) : -1);
   p->hbm_plan = nullptr;
+  p->h2 = nullptr;
   p->amplitude = 0;
   qc_find_diag_runs(p);
-  p->lead_rx = n_gates >= n_qubits ? 1 : 0;   // RX(p_w) right after the embedding RX(a_w), wire by wire, distinct slots
-  for (int g = 0; g < n_qubits && p->lead_rx; ++g)
-    if (h[g].op != QC_RX || h[g].ba != n_qubits - 1 - g || h[g].slot < 0) p->lead_rx = 0;
-  for (int g = 0; g < n_qubits && p->lead_rx; ++g)
-    for (int k = 0; k < g; ++k)
-      if (h[k].slot == h[g].slot) p->lead_rx = 0;
+  p->lead_rx = detect_lead_rx(h, n_gates, n_qubits);
   hipError_t e = hipMalloc((void**)&p->d_gates, sizeof(QcGate) * n_gates);
   if (e == hipSuccess) e = hipMemcpy(p->d_gates, h, sizeof(QcGate) * n_gates, hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -137,7 +169,9 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   }
   if (n_qubits >= 9 && n_qubits <= 20) {
     p->hbm_plan = qc_hbm_plan_create(p);
-    if (!p->hbm_plan) {
+    p->h2 = p->hbm_plan ? qc_h2_create(p, (p->lead_rx && absorb_enabled()) ? 1 : 0) : nullptr;
+    if (!p->hbm_plan || !p->h2) {
+      if (p->hbm_plan) qc_hbm_plan_destroy((QcHbmPlan*)p->hbm_plan);
       (void)hipFree(p->d_gates);
       free(h);
       free(p);
@@ -151,6 +185,7 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
 int qc_program_destroy(qc_program* p) {
   if (!p) return QC_ERR_ARG;
   if (p->hbm_plan) qc_hbm_plan_destroy((QcHbmPlan*)p->hbm_plan);
+  if (p->h2) qc_h2_destroy(p->h2);
   if (p->d_gates) (void)hipFree(p->d_gates);
   free(p->h_gates);
   free(p);
@@ -202,13 +237,37 @@ static int check_circuit(const qc_program* p, const void* trig, const float* uma
 
 size_t qc_circuit_workspace_bytes(const qc_program* p, int nch, int backward) {
   if (!p || !use_hbm(p->n_qubits) || (nch != 1 && nch != 6)) return 0;
+  if (use_h2(p)) return qc_h2_bytes(p, p->h2, nch, backward != 0, 1);
   return qc_hbm_workspace_bytes(p, nch, backward != 0);
 }
 
+size_t qc_circuit_workspace_bytes_batch(const qc_program* p, int nch, int backward, int64_t B) {
+  if (!p || B <= 0 || !use_hbm(p->n_qubits) || (nch != 1 && nch != 6)) return 0;
+  if (!use_h2(p)) return qc_hbm_workspace_bytes(p, nch, backward != 0);
+  const int64_t tiles = qc_ceil_div(B, 64);
+  const size_t all = qc_h2_bytes(p, p->h2, nch, backward != 0, tiles);
+  if ((double)all <= hbm_budget_bytes()) return all;
+  int64_t fit = qc_h2_tiles_that_fit(p, p->h2, nch, backward != 0, (size_t)hbm_budget_bytes());
+  return qc_h2_bytes(p, p->h2, nch, backward != 0, fit < 1 ? 1 : fit);
+}
+
+static size_t round256(size_t v);
 static size_t hbm_base_bytes(const qc_program* p) { return (qc_hbm_workspace_bytes(p, 6, true) + 255) & ~(size_t)255; }
-static size_t step_circuit_bytes(const qc_program* p, int64_t B_res) {
-  // n >= 9: the per-tile scratch, plus (when it fits the budget) one [chi | lam] slot per residual tile so the
-  // adjoint pass of the step starts from the forward pass's final states instead of recomputing them
+// h2, fused step: residual tiles (6 channels) and value tiles (1 channel) each keep their own resident slots
+static size_t h2_res_bytes(const qc_program* p, int64_t B_res) {
+  return B_res > 0 ? ((qc_h2_bytes(p, p->h2, 6, true, qc_ceil_div(B_res, 64)) + 255) & ~(size_t)255) : 0;
+}
+static size_t h2_val_bytes(const qc_program* p, int64_t B_val) {
+  return B_val > 0 ? ((qc_h2_bytes(p, p->h2, 1, true, qc_ceil_div(B_val, 64)) + 255) & ~(size_t)255) : 0;
+}
+static size_t h2_min_bytes(const qc_program* p) { return (qc_h2_bytes(p, p->h2, 6, true, 1) + 255) & ~(size_t)255; }
+static size_t step_circuit_bytes(const qc_program* p, int64_t B_res, int64_t B_val = 0) {
+  if (use_hbm(p->n_qubits) && use_h2(p)) {
+    const size_t all = h2_res_bytes(p, B_res) + h2_val_bytes(p, B_val);
+    return (double)all <= hbm_budget_bytes() ? (all > h2_min_bytes(p) ? all : h2_min_bytes(p)) : h2_min_bytes(p);
+  }
+  // round-1 kernels, n >= 9: the per-tile scratch, plus (when it fits the budget) one [chi | lam] slot per residual tile
+  // so the adjoint pass of the step starts from the forward pass's final states instead of recomputing them
   if (use_hbm(p->n_qubits)) return hbm_base_bytes(p) + qc_hbm_keep_bytes(p, B_res);
   if (use_reg(p->n_qubits)) return qc_reg_chi_store_bytes(p, B_res);   // optional: enables the no-recompute adjoint
   if (use_wave(p->n_qubits)) return qc_wave_chi_store_bytes(p, B_res);   // same, compile-time programs at n = 6..8
@@ -216,9 +275,20 @@ static size_t step_circuit_bytes(const qc_program* p, int64_t B_res) {
 }
 static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+int qc_hbm_plan_describe(const int32_t* rows, int n_gates, int n_qubits, int n_params, int32_t* out, int cap) {
+  if (!rows || n_gates <= 0 || n_qubits < 9 || n_qubits > 20 || n_params < 0 || cap < 0) return 0;
+  QcGate* h = (QcGate*)malloc(sizeof(QcGate) * n_gates);
+  if (!h) return 0;
+  int n_u4 = 0, len = 0;
+  if (parse_rows(rows, n_gates, n_qubits, n_params, h, &n_u4))
+    len = qc_h2_describe_gates(h, n_gates, n_qubits, (detect_lead_rx(h, n_gates, n_qubits) && absorb_enabled()) ? 1 : 0, out, cap);
+  free(h);
+  return len;
+}
+
 size_t qc_step_workspace_bytes(const qc_program* p, int64_t B_res, int64_t B_val) {
   if (!p || B_res < 0 || B_val < 0) return 0;
-  size_t b = round256(step_circuit_bytes(p, B_res));
+  size_t b = round256(step_circuit_bytes(p, B_res, B_val));
   if (p->amplitude)   // initial-amplitude jets and their cotangents, both pipelines
     b += 2 * round256(sizeof(float) * 6 * p->n_qubits * (size_t)B_res) + 2 * round256(sizeof(float) * p->n_qubits * (size_t)B_val);
   return b;
@@ -230,7 +300,8 @@ int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, 
   if (rc) return rc;
   if (!angles || !expval) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = qc_hbm_forward(p, (const QcTrig*)trig, umat, angles, expval, B, 1, ws, ws_bytes, (hipStream_t)stream);
+    rc = use_h2(p) ? qc_h2_forward(p, p->h2, (const QcTrig*)trig, umat, angles, expval, B, 1, ws, ws_bytes, false, (hipStream_t)stream)
+                   : qc_hbm_forward(p, (const QcTrig*)trig, umat, angles, expval, B, 1, ws, ws_bytes, (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
@@ -246,8 +317,10 @@ int qc_backward_expval(const qc_program* p, const void* trig, const float* umat,
   if (rc) return rc;
   if (!angles || !cot || !d_angles || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = qc_hbm_backward(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, 1, ws,
-                         ws_bytes, (hipStream_t)stream);
+    rc = use_h2(p) ? qc_h2_backward(p, p->h2, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, 1, ws,
+                                    ws_bytes, false, (hipStream_t)stream)
+                   : qc_hbm_backward(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, 1, ws,
+                                     ws_bytes, (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
@@ -264,7 +337,8 @@ int qc_forward_jets(const qc_program* p, const void* trig, const float* umat, co
   if (rc) return rc;
   if (!ajets || !qjets) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = qc_hbm_forward(p, (const QcTrig*)trig, umat, ajets, qjets, B, 6, ws, ws_bytes, (hipStream_t)stream);
+    rc = use_h2(p) ? qc_h2_forward(p, p->h2, (const QcTrig*)trig, umat, ajets, qjets, B, 6, ws, ws_bytes, false, (hipStream_t)stream)
+                   : qc_hbm_forward(p, (const QcTrig*)trig, umat, ajets, qjets, B, 6, ws, ws_bytes, (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
@@ -280,8 +354,10 @@ int qc_backward_jets(const qc_program* p, const void* trig, const float* umat, c
   if (rc) return rc;
   if (!ajets || !qbar || !abar || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = qc_hbm_backward(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, 6, ws, ws_bytes,
-                         (hipStream_t)stream);
+    rc = use_h2(p) ? qc_h2_backward(p, p->h2, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, 6, ws,
+                                    ws_bytes, false, (hipStream_t)stream)
+                   : qc_hbm_backward(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, 6, ws, ws_bytes,
+                                     (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
@@ -487,6 +563,22 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
     // the two pipelines are independent until the row reduction: fork the value pipeline onto a side
     // stream (not for n >= 9, where both would share the HBM statevector workspace)
     QcSide* side = (d->B_res > 0 && d->B_val > 0 && !use_hbm(n)) ? side_stream() : nullptr;
+    // n >= 9 (round-structured plan): residual and value tiles keep their own resident slots when the caller's
+    // workspace holds them all; otherwise both pipelines share the workspace and the adjoint pass recomputes
+    const bool h2 = use_hbm(n) && use_h2(d->prog);
+    bool h2_resident = false;
+    void *h2_res_ws = cws, *h2_val_ws = cws;
+    size_t h2_res_b = cws_bytes, h2_val_b = cws_bytes;
+    if (h2) {
+      if (!cws || cws_bytes < h2_min_bytes(d->prog)) return QC_ERR_ARG;
+      const size_t rb = h2_res_bytes(d->prog, d->B_res), vb = h2_val_bytes(d->prog, d->B_val);
+      h2_resident = cws_bytes >= rb + vb;
+      if (h2_resident) {
+        h2_res_b = rb;
+        h2_val_ws = (char*)cws + rb;
+        h2_val_b = vb;
+      }
+    }
     hipStream_t sv = st;
     if (side) {
       if (hipEventRecord(side->fork, st) != hipSuccess || hipStreamWaitEvent(side->s, side->fork, 0) != hipSuccess)
@@ -501,12 +593,18 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (amp && (rc = qc_amp_forward(d->ajets_val_dev, u_val, n, d->B_val, 1, sv))) return rc;
       const float* cin_val = amp ? u_val : d->ajets_val_dev;
       float* cout_val = amp ? ub_val : d->abar_val_dev;
-      if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, cin_val, d->qjets_val_dev, d->B_val, cws, cws_bytes, sv))) return rc;
+      if (h2) {
+        if ((rc = qc_h2_forward(d->prog, d->prog->h2, trig, d->umat_dev, cin_val, d->qjets_val_dev, d->B_val, 1, h2_val_ws, h2_val_b,
+                                h2_resident, sv))) return rc;
+      } else if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, cin_val, d->qjets_val_dev, d->B_val, cws, cws_bytes, sv))) return rc;
       if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev,
                         d->abar_val_dev, nullptr, nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride,
                         rows_res, d->B_val, 1, sv))) return rc;
-      if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, cin_val, d->qbar_val_dev, cout_val,
-                                   d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, cws, cws_bytes, sv))) return rc;
+      if (h2) {
+        if ((rc = qc_h2_backward(d->prog, d->prog->h2, trig, d->umat_dev, cin_val, d->qbar_val_dev, cout_val, d->part_dev + L.oTh,
+                                 d->part_stride, rows_res, d->B_val, 1, h2_val_ws, h2_val_b, h2_resident, sv))) return rc;
+      } else if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, cin_val, d->qbar_val_dev, cout_val,
+                                          d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, cws, cws_bytes, sv))) return rc;
       if (amp && (rc = qc_amp_backward(d->ajets_val_dev, ub_val, d->abar_val_dev, n, d->B_val, 1, sv))) return rc;
       if ((rc = qc_pre_backward(d->X_val_dev, d->params_dev, H, n, d->n_theta, d->abar_val_dev, d->part_dev,
                                 d->part_stride, rows_res, d->B_val, 1, sv))) return rc;
@@ -524,7 +622,7 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
           cws_bytes >= qc_wave_chi_store_bytes(d->prog, d->B_res))
         wave_store = (float*)cws;
       void* hbm_store = nullptr;
-      if (use_hbm(n) && cws && qc_hbm_keep_bytes(d->prog, d->B_res) > 0 &&
+      if (use_hbm(n) && !h2 && cws && qc_hbm_keep_bytes(d->prog, d->B_res) > 0 &&
           cws_bytes >= hbm_base_bytes(d->prog) + qc_hbm_keep_bytes(d->prog, d->B_res))
         hbm_store = (char*)cws + hbm_base_bytes(d->prog);
       if (amp && (rc = qc_amp_forward(d->ajets_res_dev, u_res, n, d->B_res, 6, st))) return rc;
@@ -536,6 +634,10 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
         if ((rc = after_launch())) return rc;
       } else if (wave_store) {
         if ((rc = qc_wave_jets_fwd(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, wave_store, st))) return rc;
+        if ((rc = after_launch())) return rc;
+      } else if (h2) {
+        if ((rc = qc_h2_forward(d->prog, d->prog->h2, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, 6, h2_res_ws, h2_res_b,
+                                h2_resident, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if (hbm_store) {
         if ((rc = qc_hbm_forward_keep(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, cws, hbm_base_bytes(d->prog),
@@ -554,6 +656,10 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       } else if (wave_store) {
         if ((rc = qc_wave_jets_bwd(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,
                                    d->part_stride, 0, d->B_res, wave_store, st))) return rc;
+        if ((rc = after_launch())) return rc;
+      } else if (h2) {
+        if ((rc = qc_h2_backward(d->prog, d->prog->h2, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,
+                                 d->part_stride, 0, d->B_res, 6, h2_res_ws, h2_res_b, h2_resident, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if (hbm_store) {
         if ((rc = qc_hbm_backward_kept(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,

@@ -1,0 +1,1225 @@
+// Variational-circuit kernels, "hbm" family, staged execution (plan: qc_hbm2_plan.h): 9 <= n <= 20 qubits,
+// statevectors resident in HBM, angle encoding.  Replaces the PennyLane default.qubit simulation behind
+// DVQuantumLayer.forward (reference nn/DVQuantumLayer.py:151-154,176-214) and the torch double-backward through it
+// (nn/pde.py:59-70 + loss.backward()) for the 16-qubit cross_mesh configuration.
+//
+// Memory: every 64-point tile owns one SLOT [chi: nch][64][2^n] [lam: nch][64][2^n] (complex64).  A launch covers ALL
+// tiles that fit the workspace; a block = (point, tile of 2^nloc amplitudes) and walks the channels of its point one
+// after the other, so that what couples the channels stays on chip:
+//   forward   stage 0 GENERATES the embedded product state and its derivative series in LDS (no init pass);
+//             the last stage reduces <Z_w> and its jets against the value channel's tile held in registers (no
+//             read-back pass) and leaves the final states in the slot for the adjoint sweep;
+//   backward  the last stage builds the cotangents lam_c from the final states on load (lam_0 accumulates in
+//             registers over the channel loop), every stage un-applies its rounds on (chi, lam) and accumulates
+//             Im<lam|G|chi> per gate; diagonal tables: t = sum_c Im(conj lam chi) in registers, one Walsh-Hadamard
+//             transform per tile, coefficients of weight <= 2; stage 0 finally un-embeds lam (RX^dagger of the
+//             local wires) and writes only its amplitudes of weight <= 3: the cotangents of the angle jets are sparse
+//             inner products in that frame (qc_gates.h, "pulled-back frame").
+// HBM traffic per channel-evaluation at n = 16 cross_mesh (2 stages): forward 1 write + 1 read + 1 write (kept
+// final state), backward 1 read + 2 writes + 2 reads  ->  8 state transfers for forward + adjoint against the
+// SURVEY §8(d) minimum of 4; the round-1 kernels moved ~56.
+#include "qc_internal.h"
+#include "qc_gates.h"
+#include "qc_hbm2_plan.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+struct Cplx {
+  float re, im;
+};
+
+constexpr int H2_XW = 24;   // floats per <Z> partial record (n <= 20 used)
+
+// ---- device copy of the plan
+struct H2Dev {
+  H2Plan plan;
+  H2Round* d_rounds = nullptr;
+  H2Gate* d_gates = nullptr;
+  H2DiagGate* d_dgates = nullptr;
+  int* d_sparse = nullptr;      // local indices of weight <= 3 (first stage's tile)
+  int* d_rank = nullptr;        // inverse: local index -> position in d_sparse, or -1
+  int* d_whtidx = nullptr;      // local masks of weight 0, 1, 2 (coefficient order of the table gradients)
+  int* d_pslots = nullptr;      // per stage: parameter slot of in-round parametric gate pidx; offsets in pslot_off
+  std::vector<int> pslot_off;
+  int nx = 0, nc = 0;
+};
+
+// LDS swizzle of a local index (8-byte slots; a half-wave of 32 lanes must hit 32 distinct slots mod 32).  The lanes of
+// a round vary the local positions outside its register group; linear maps of the low 5 bits chosen so that every
+// group pattern of the tile (and the linear load / store pattern) is conflict-free:
+//   RB = 4 (groups {0-3}, {4-7}, {8-11}):          low5 ^= idx[5..8], bit 4 ^= idx[8]
+//   RB = 3 (groups {0-2}, {3-5}, {6-8}, {9-11}):   bit 2 ^= idx5, bits {0, 3} ^= idx6, bits {1, 4} ^= idx7
+template <int RB>
+__device__ __forceinline__ int h2_swz(int l) {
+  if constexpr (RB == 3)
+    return l ^ (((l >> 5) & 1) << 2) ^ (((l >> 6) & 1) * 9) ^ (((l >> 7) & 1) * 18);
+  else
+    return l ^ ((l >> 5) & 15) ^ (((l >> 8) & 1) << 4);
+}
+__device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ Cplx cmulc(Cplx a, Cplx b) { return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }
+
+// ---------------------------------------------------------------- per-point, per-wire embedding data
+// wd[pt][w][8] = {cos, sin of (a_w + theta_w)/2, da_t, da_x, da_y, dda_xx, dda_yy, 0}, pt = point within the launch group
+template <int NCH>
+__global__ void k_h2_wiredata(const float* __restrict__ ajets, int64_t B, int64_t p_first, int64_t npts, int n,
+                              float* __restrict__ wd, const QcTrig* __restrict__ trig, int absorb) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npts * n) return;
+  const int64_t p = p_first + i / n;
+  const int w = (int)(i % n);
+  float* o = wd + (size_t)i * 8;
+  const float a = ajets[(int64_t)w * B + p] + (absorb ? trig[w].th : 0.f);
+  float s, c;
+  sincosf(0.5f * a, &s, &c);
+  o[0] = c;
+  o[1] = s;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) o[2 + k] = 0.f;
+  if constexpr (NCH == 6) {
+    for (int k = 0; k < 3; ++k) o[2 + k] = ajets[((int64_t)(1 + k) * n + w) * B + p];
+    for (int k = 0; k < 2; ++k) o[5 + k] = ajets[((int64_t)(4 + k) * n + w) * B + p];
+  }
+}
+
+// phase table of one diagonal run: tab[k] = prod_g phase_g(k), accumulated in double
+__global__ void __launch_bounds__(256) k_h2_diag_table(const H2DiagGate* __restrict__ dg, int ng,
+                                                       const QcTrig* __restrict__ trig, int n, Cplx* __restrict__ tab) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= ((int64_t)1 << n)) return;
+  double zr = 1.0, zi = 0.0;
+  for (int i = 0; i < ng; ++i) {
+    const H2DiagGate g = dg[i];
+    if (g.bc >= 0 && !((k >> g.bc) & 1)) continue;
+    const QcTrig tr = trig[g.gi];
+    const double c = tr.c, s = ((k >> g.bt) & 1) ? (double)tr.s : -(double)tr.s;   // bit 0: c - i s, bit 1: c + i s
+    const double nr = zr * c - zi * s, ni = zr * s + zi * c;
+    zr = nr;
+    zi = ni;
+  }
+  tab[k] = {(float)zr, (float)zi};
+}
+
+// ---------------------------------------------------------------- stage kernel
+struct H2Args {
+  Cplx* store;           // tile slots
+  int64_t slot_elems;    // complex64 elements per slot = 2 * nch * 64 * 2^n
+  int64_t B;             // points of the call ([feature][B] arrays)
+  int64_t p_first;       // point index of (tile 0, t = 0) of this launch
+  int64_t pt_stride;     // points covered by this launch rounded up to 64 (row stride of the partial buffers)
+  int n;
+  int first, last;       // this stage is the first / last of the plan
+  int keep_final;        // forward, last stage: leave the final states in the slot
+  H2Stage sd;
+  const H2Round* rounds;
+  const H2Gate* gates;
+  const QcTrig* trig;
+  const float* umat;
+  const Cplx* tabs;      // [n_tables][2^n]
+  const float* wd;       // [pt_stride][n][8]
+  float* xpart;          // forward, last stage: [8][pt_stride][ntau][H2_XW]
+  const float* qbar;     // backward, last stage: [nch][n][B]
+  float* gpart;          // backward: [np][pt_stride * ntau] partials of the in-round parametric gates
+  float* dpart;          // backward: [ntab][pt_stride * ntau][nc] Walsh-Hadamard coefficients of t
+  Cplx* xi;              // backward, first stage: [nch][pt_stride][ntau][nx] un-embedded cotangents, weight <= 3
+  const int* sparse_idx;
+  const int* wht_idx;
+  int nx, nc;
+};
+
+// Plan records are read with wave-uniform addresses; readfirstlane tells the compiler so (SGPRs instead of VGPRs for
+// every index, offset and coefficient derived from them).
+__device__ __forceinline__ int h2_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float h2_unif(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ H2Round h2_load_round(const H2Round* p) {
+  H2Round r;
+  r.kind = h2_uni(p->kind);
+  r.nrb = h2_uni(p->nrb);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r.rb[j] = h2_uni(p->rb[j]);
+  r.g0 = h2_uni(p->g0);
+  r.ng = h2_uni(p->ng);
+  r.table = h2_uni(p->table);
+  r.tslot = h2_uni(p->tslot);
+  return r;
+}
+__device__ __forceinline__ H2Gate h2_load_gate(const H2Gate* p) {
+  H2Gate g;
+  g.op = h2_uni(p->op);
+  g.kind = h2_uni(p->kind);
+  g.tq = h2_uni(p->tq);
+  g.cq = h2_uni(p->cq);
+  g.tbit = h2_uni(p->tbit);
+  g.cbit = h2_uni(p->cbit);
+  g.gi = h2_uni(p->gi);
+  g.slot = h2_uni(p->slot);
+  g.pidx = h2_uni(p->pidx);
+  return g;
+}
+
+// one-bit X (the CNOT body under a predicate)
+template <int N, int B>
+__device__ __forceinline__ void g_x(SV<N>& v) {
+#pragma unroll
+  for (int k = 0; k < (1 << (N - 1)); ++k) {
+    const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
+    const float ar = v.re[i0], ai = v.im[i0];
+    v.re[i0] = v.re[i1];
+    v.im[i0] = v.im[i1];
+    v.re[i1] = ar;
+    v.im[i1] = ai;
+  }
+}
+
+template <int N, int K>
+__device__ __forceinline__ void h2_apply_x(SV<N> (&v)[K], int tq) {
+  switch (tq) {
+// (the empty asm with a per-case immediate keeps the optimiser from merging the cases into one body with
+// run-time register indices, which would move the amplitude arrays to scratch memory)
+#define HX_(BIT) case BIT: if constexpr (BIT < N) { _Pragma("unroll") for (int q = 0; q < K; ++q) g_x<N, BIT>(v[q]); } asm volatile("" ::"n"(BIT)); break;
+    HX_(0) HX_(1) HX_(2) HX_(3)
+#undef HX_
+    default: break;
+  }
+}
+
+template <int N, int K>
+__device__ __forceinline__ void h2_apply_u4(SV<N> (&v)[K], int hq, int lq, const float* __restrict__ u) {
+  if constexpr (N >= 2) {
+    switch (hq * 4 + lq) {
+#define HU_(HB, LB)                                                                       \
+  case (HB * 4 + LB):                                                                     \
+    if constexpr (HB < N && LB < N && HB != LB) {                                         \
+      _Pragma("unroll") for (int q = 0; q < K; ++q) g_u4<N, HB, LB>(v[q], u);             \
+    }                                                                                     \
+    asm volatile("" ::"n"(HB * 4 + LB));                                                  \
+    break;
+      HU_(0, 1) HU_(0, 2) HU_(0, 3) HU_(1, 0) HU_(1, 2) HU_(1, 3) HU_(2, 0) HU_(2, 1) HU_(2, 3) HU_(3, 0) HU_(3, 1) HU_(3, 2)
+#undef HU_
+      default: break;
+    }
+  }
+}
+
+// MODE 0: forward.  MODE 1: backward (chi and lam).  RB register bits per round, NT = 2^(nloc - RB) threads.
+template <int RB, int NCH, int MODE>
+__global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_stage(const H2Args A) {
+  constexpr bool BWD = MODE == 1;
+  constexpr int R = 1 << RB;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  const H2Stage& sd = A.sd;
+  const int nloc = sd.nloc, TS = 1 << nloc, NT = TS >> RB;
+  Cplx* t0 = reinterpret_cast<Cplx*>(smem_raw);          // chi tile
+  Cplx* t1 = t0 + (BWD ? TS : 0);                        // lam tile (backward)
+  __shared__ int s_depA[64], s_depB[64];                 // local index -> global offset, low / high 6 positions
+  __shared__ float s_tabA[64][3], s_tabB[64][3];         // series factors of the tile (forward generation)
+  __shared__ float s_D[6][128];                          // backward: D_c = g + A[l & 63] + B[l >> 6]
+  __shared__ float s_Dg[6];
+  __shared__ float s_g[8][H2_MAXP];                      // per-wave sums of the in-round gate gradients
+  __shared__ float s_red[8][H2_XW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NW = (NT + 63) >> 6;
+  const int n = A.n;
+  const int64_t N = (int64_t)1 << n;
+  const int ntau = 1 << sd.ngb;
+  const int tau = blockIdx.x % ntau;
+  const int64_t pt = blockIdx.x / ntau;                  // point index within this launch
+  const int64_t p = A.p_first + pt;
+  const bool live = p < A.B;
+  const int64_t tile64 = pt >> 6;
+  const int t = (int)(pt & 63);
+  const int64_t blk = (int64_t)pt * ntau + tau;          // row of this block in the partial buffers
+  const int64_t nblk = A.pt_stride * ntau;
+
+  if (!live) {   // ragged tail: the folds read every row
+    if constexpr (BWD) {
+      for (int i = tid; i < sd.np; i += NT) A.gpart[(size_t)i * nblk + blk] = 0.f;
+      for (int k = 0; k < sd.ntab; ++k)
+        for (int i = tid; i < A.nc; i += NT) A.dpart[((size_t)k * nblk + blk) * A.nc + i] = 0.f;
+    }
+    return;
+  }
+  // global offset of the tile and of a local index
+  int64_t abase = 0;
+  for (int j = 0; j < sd.ngb; ++j)
+    if ((tau >> j) & 1) abase |= (int64_t)1 << sd.gb[j];
+  if (tid < 64) {
+    int a = 0, b = 0;
+    for (int j = 0; j < 6 && j < nloc; ++j)
+      if ((tid >> j) & 1) a |= 1 << sd.lb[j];
+    for (int j = 6; j < nloc; ++j)
+      if ((tid >> (j - 6)) & 1) b |= 1 << sd.lb[j];
+    s_depA[tid] = a;
+    s_depB[tid] = b;
+  }
+  if constexpr (BWD) {
+    for (int i = tid; i < 8 * H2_MAXP; i += NT) (&s_g[0][0])[i] = 0.f;
+  }
+  auto dep = [&](int l) { return (int64_t)(s_depA[l & 63] | s_depB[l >> 6]); };
+  const float* wdp = A.wd + (size_t)pt * n * 8;
+  Cplx* slot = A.store + (size_t)tile64 * A.slot_elems;
+  auto chi_of = [&](int c) { return slot + ((size_t)c * 64 + t) * N; };
+  auto lam_of = [&](int c) { return slot + ((size_t)(NCH + c) * 64 + t) * N; };
+
+  // registers that live across the channel loop
+  Cplx x0[BWD ? 1 : R];       // forward, last stage: final value-channel tile
+  Cplx l0acc[BWD ? R : 1];    // backward, last stage: lam_0 = sum_c D_c chi_c
+  float tacc0[BWD ? R : 1], tacc1[BWD ? R : 1];   // backward: t = sum_c Im(conj lam chi) at the stage's tables
+  if constexpr (BWD) {
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      l0acc[q] = {0.f, 0.f};
+      tacc0[q] = 0.f;
+      tacc1[q] = 0.f;
+    }
+  }
+  __syncthreads();
+
+  if constexpr (BWD) {
+    if (A.last) {
+      // D_c[k] = sum_w (+-) qbar[c][w][p] by index bit n-1-w: constant part (non-local bits) + two 64-entry tables
+      for (int i = tid; i < NCH * 128; i += NT) {
+        const int c = i >> 7, e = i & 127, half = e >> 6, v = e & 63;
+        float s = 0.f;
+        const int j0 = half ? 6 : 0, j1 = half ? nloc : (nloc < 6 ? nloc : 6);
+        for (int j = j0; j < j1; ++j) {
+          const float qb = A.qbar[((int64_t)c * n + (n - 1 - sd.lb[j])) * A.B + p];
+          s += ((v >> (j - j0)) & 1) ? -qb : qb;
+        }
+        s_D[c][e] = s;
+      }
+      if (tid < NCH) {
+        float s = 0.f;
+        for (int j = 0; j < sd.ngb; ++j) {
+          const float qb = A.qbar[((int64_t)tid * n + (n - 1 - sd.gb[j])) * A.B + p];
+          s += ((tau >> j) & 1) ? -qb : qb;
+        }
+        s_Dg[tid] = s;
+      }
+      __syncthreads();
+    }
+  }
+  auto Dval = [&](int c, int l) { return s_Dg[c] + s_D[c][l & 63] + s_D[c][64 + (l >> 6)]; };
+
+  // ------------------------------------------------------------------ channel loop
+  for (int ci = 0; ci < NCH; ++ci) {
+    // backward: the value channel last (its cotangent needs every other channel's final state)
+    const int c = BWD ? (ci + 1 < NCH ? ci + 1 : 0) : ci;
+    // ---------------- load phase (linear mapping: thread tid owns local indices tid + NT q)
+    if constexpr (!BWD) {
+      if (A.first) {
+        // generate channel c of the embedded product state: series (P0, P1, P2) of the tile = G (x) A (x) B
+        const int ord = c == 0 ? 0 : (c <= 3 ? 1 : 2);
+        const int dsel = c == 0 ? 0 : (c <= 3 ? c - 1 : c - 3);      // direction: t, x, y
+        const int ddsel = c >= 4 ? c - 4 : 0;
+        auto step = [&](float& P0, float& P1, float& P2, int bit_pos, int bitval) {
+          const float* w8 = wdp + (size_t)(n - 1 - bit_pos) * 8;
+          const float cw = w8[0], sw = w8[1];
+          const float da = ord >= 1 ? w8[2 + dsel] : 0.f, dda = ord >= 2 ? w8[5 + ddsel] : 0.f;
+          const float w0 = bitval ? sw : cw, e = bitval ? cw : -sw;
+          const float w1 = 0.5f * da * e, w2 = 0.5f * dda * e - 0.25f * da * da * w0;
+          const float p0 = P0, p1 = P1, p2 = P2;
+          P0 = p0 * w0;
+          P1 = p0 * w1 + p1 * w0;
+          P2 = p0 * w2 + 2.f * p1 * w1 + p2 * w0;
+        };
+        for (int e_ = tid; e_ < 128; e_ += NT) {
+          const int half = e_ >> 6, v = e_ & 63;
+          float P0 = 1.f, P1 = 0.f, P2 = 0.f;
+          if (half == 0) {   // the non-local bits are folded into table A
+            for (int j = 0; j < sd.ngb; ++j) step(P0, P1, P2, sd.gb[j], (tau >> j) & 1);
+            for (int j = 0; j < 6 && j < nloc; ++j) step(P0, P1, P2, sd.lb[j], (v >> j) & 1);
+            s_tabA[v][0] = P0; s_tabA[v][1] = P1; s_tabA[v][2] = P2;
+          } else {
+            for (int j = 6; j < nloc; ++j) step(P0, P1, P2, sd.lb[j], (v >> (j - 6)) & 1);
+            s_tabB[v][0] = P0; s_tabB[v][1] = P1; s_tabB[v][2] = P2;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int l = tid + NT * q;
+          const float a0 = s_tabA[l & 63][0], a1 = s_tabA[l & 63][1], a2 = s_tabA[l & 63][2];
+          const float b0 = s_tabB[l >> 6][0], b1 = s_tabB[l >> 6][1], b2 = s_tabB[l >> 6][2];
+          const float m = ord == 0 ? a0 * b0 : (ord == 1 ? a1 * b0 + a0 * b1 : a0 * b2 + 2.f * a1 * b1 + a2 * b0);
+          const int ph = __popcll((unsigned long long)(abase | dep(l))) & 3;
+          Cplx v;
+          v.re = ph == 0 ? m : (ph == 2 ? -m : 0.f);
+          v.im = ph == 1 ? -m : (ph == 3 ? m : 0.f);
+          t0[h2_swz<RB>(l)] = v;
+        }
+      } else {
+        const Cplx* g = chi_of(c);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int l = tid + NT * q;
+          t0[h2_swz<RB>(l)] = g[abase | dep(l)];
+        }
+      }
+    } else {
+      const Cplx* g = chi_of(c);
+      const Cplx* gl = lam_of(c);
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int l = tid + NT * q;
+        const int64_t a = abase | dep(l);
+        Cplx x = g[a];
+        Cplx y;
+        if (A.last) {
+          // (the value channel's final tile is re-read per channel: 32 KiB from L2 instead of 32 live registers)
+          const Cplx xv = c == 0 ? x : chi_of(0)[a];
+          // cotangents of the final states: lam_0 = sum_c D_c chi_c, lam_t = D_t chi_0,
+          // lam_x = D_x chi_0 + 2 D_xx chi_x, lam_xx = D_xx chi_0 (same for y)   [DESIGN.md §3]
+          if (c == 0) {
+            const float d = Dval(0, l);
+            y = {l0acc[q].re + d * x.re, l0acc[q].im + d * x.im};
+          } else {
+            const float d = Dval(c, l);
+            y = {d * xv.re, d * xv.im};
+            if (c == 2 || c == 3) {
+              const float d2 = 2.f * Dval(c + 2, l);
+              y.re += d2 * x.re;
+              y.im += d2 * x.im;
+            }
+            l0acc[q].re += d * x.re;
+            l0acc[q].im += d * x.im;
+          }
+        } else {
+          y = gl[a];
+        }
+        t0[h2_swz<RB>(l)] = x;
+        t1[h2_swz<RB>(l)] = y;
+        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four loads in flight per array, not sixteen (registers)
+      }
+    }
+    __syncthreads();
+
+    // ---------------- rounds
+    for (int ri = 0; ri < sd.nr; ++ri) {
+      const H2Round rd = h2_load_round(A.rounds + sd.r0 + (BWD ? sd.nr - 1 - ri : ri));
+      if (rd.kind == H2_ROUND_TABLE) {
+        const Cplx* tab = A.tabs + (size_t)rd.table * N;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int l = tid + NT * q;
+          const Cplx ph = tab[abase | dep(l)];
+          const int li = h2_swz<RB>(l);
+          if constexpr (!BWD) {
+            t0[li] = cmul(t0[li], ph);
+          } else {
+            const Cplx x = t0[li], y = t1[li];
+            const float tv = y.re * x.im - y.im * x.re;   // Im(conj(lam) chi), invariant under the run's gates
+            if (rd.tslot == 0) tacc0[q] += tv;
+            else tacc1[q] += tv;
+            t0[li] = cmulc(x, ph);
+            t1[li] = cmulc(y, ph);
+          }
+          if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        continue;
+      }
+      // gate round: register bits rd.rb[], lane bits = the other local positions
+      int regmask = 0;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) regmask |= 1 << rd.rb[j];
+      int lbase = 0;
+      {
+        int tb = tid;
+        for (int pos = 0; pos < nloc; ++pos)
+          if (!((regmask >> pos) & 1)) {
+            lbase |= (tb & 1) << pos;
+            tb >>= 1;
+          }
+      }
+      int roff[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        int o = 0;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) o |= ((q >> j) & 1) << rd.rb[j];
+        roff[q] = o;
+      }
+      SV<RB> v[BWD ? 2 : 1];
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int li = h2_swz<RB>(lbase | roff[q]);
+        const Cplx x = t0[li];
+        v[0].re[q] = x.re;
+        v[0].im[q] = x.im;
+        if constexpr (BWD) {
+          const Cplx y = t1[li];
+          v[1].re[q] = y.re;
+          v[1].im[q] = y.im;
+        }
+      }
+      const int64_t alane = abase | dep(lbase);   // global index of this thread's amplitudes, register bits clear
+      for (int gi = 0; gi < rd.ng; ++gi) {
+        const H2Gate hg = h2_load_gate(A.gates + rd.g0 + (BWD ? rd.ng - 1 - gi : gi));
+        float c_ = 1.f, s_ = 0.f;
+        if (hg.op != QC_U4 && hg.slot >= 0) {
+          c_ = h2_unif(A.trig[hg.gi].c);
+          s_ = h2_unif(A.trig[hg.gi].s);
+        }
+        float grad = 0.f;
+        switch (hg.kind) {
+          case H2_K_REG1:
+          case H2_K_REG2: {
+            QcGate gg;
+            gg.op = hg.op;
+            gg.ba = hg.kind == H2_K_REG2 ? hg.cq : hg.tq;
+            gg.bb = hg.kind == H2_K_REG2 ? hg.tq : -1;
+            gg.slot = hg.slot;
+            if constexpr (BWD) {
+              if (hg.pidx >= 0) grad = qc_gate_grad<RB>(v[1], v[0], gg);
+            }
+            qc_apply_gate<RB, BWD ? 2 : 1, BWD>(v, gg, c_, s_, A.umat);
+            break;
+          }
+          case H2_K_PRED: {
+            const bool on = (alane >> hg.cbit) & 1;
+            if (on) {
+              if (hg.op == QC_CNOT) {
+                h2_apply_x<RB, BWD ? 2 : 1>(v, hg.tq);
+              } else {   // CRX
+                QcGate gg;
+                gg.op = QC_RX;
+                gg.ba = hg.tq;
+                gg.bb = -1;
+                gg.slot = hg.slot;
+                if constexpr (BWD) {
+                  if (hg.pidx >= 0) grad = qc_gate_grad<RB>(v[1], v[0], gg);
+                }
+                qc_apply_gate<RB, BWD ? 2 : 1, BWD>(v, gg, c_, s_, A.umat);
+              }
+            }
+            break;
+          }
+          case H2_K_PHASE: {
+            const float sg = BWD ? -s_ : s_;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+              const int64_t a = alane | dep(roff[q]);
+              const bool on = hg.cbit < 0 || ((a >> hg.cbit) & 1);
+              const bool hi = (a >> hg.tbit) & 1;
+              if constexpr (BWD) {
+                const float tv = v[1].re[q] * v[0].im[q] - v[1].im[q] * v[0].re[q];
+                grad += on ? (hi ? -tv : tv) : 0.f;
+              }
+              const float sq = on ? (hi ? sg : -sg) : 0.f, cq = on ? c_ : 1.f;   // multiply by cq + i sq
+#pragma unroll
+              for (int k = 0; k < (BWD ? 2 : 1); ++k) {
+                const float ar = v[k].re[q], ai = v[k].im[q];
+                v[k].re[q] = cq * ar - sq * ai;
+                v[k].im[q] = cq * ai + sq * ar;
+              }
+            }
+            break;
+          }
+          case H2_K_U4: {
+            float us[32];   // the 4x4 matrix in SGPRs
+            const float* um = A.umat + (hg.slot * 2 + (BWD ? 1 : 0)) * 32;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) us[i] = h2_unif(um[i]);
+            h2_apply_u4<RB, BWD ? 2 : 1>(v, hg.tq, hg.cq, us);
+            break;
+          }
+          default: break;
+        }
+        if constexpr (BWD) {
+          if (hg.pidx >= 0) {
+            const float tot = qc_wave_sum_to_lane63(grad);
+            if (lane == 63) s_g[wave][hg.pidx] += tot;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < R; ++q) {
+        const int li = h2_swz<RB>(lbase | roff[q]);
+        t0[li] = {v[0].re[q], v[0].im[q]};
+        if constexpr (BWD) t1[li] = {v[1].re[q], v[1].im[q]};
+      }
+      __syncthreads();
+    }
+
+    // ---------------- store phase
+    if constexpr (!BWD) {
+      if (A.last) {
+        // <Z> sums of this tile against the value channel's final tile (held in x0), by index bit
+        float tot = 0.f, sq = 0.f, qs[RB], qq[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) qs[j] = qq[j] = 0.f;
+        Cplx fin[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          fin[q] = t0[h2_swz<RB>(tid + NT * q)];
+          if (c == 0) x0[q] = fin[q];
+          const float w = c == 0 ? fin[q].re * fin[q].re + fin[q].im * fin[q].im
+                                 : 2.f * (x0[q].re * fin[q].re + x0[q].im * fin[q].im);
+          const float w2 = 2.f * (fin[q].re * fin[q].re + fin[q].im * fin[q].im);
+          tot += w;
+          sq += w2;
+#pragma unroll
+          for (int j = 0; j < RB; ++j)
+            if ((q >> j) & 1) {
+              qs[j] += w;
+              qq[j] += w2;
+            }
+        }
+        const int lanebits = nloc - RB;   // local positions [0, lanebits) = thread bits, the rest = q bits
+        for (int pass = 0; pass < ((c == 2 || c == 3) ? 2 : 1); ++pass) {
+          for (int b = 0; b < n; ++b) {   // b = global index bit
+            // where does bit b live?
+            int posb = -1;
+            for (int j = 0; j < nloc; ++j)
+              if (sd.lb[j] == b) posb = j;
+            float mine;
+            const float T_ = pass ? sq : tot;
+            if (posb < 0) {
+              int jb = 0;
+              for (int j = 0; j < sd.ngb; ++j)
+                if (sd.gb[j] == b) jb = j;
+              mine = ((tau >> jb) & 1) ? -T_ : T_;
+            } else if (posb < lanebits) {
+              mine = ((tid >> posb) & 1) ? -T_ : T_;
+            } else {
+              float part = 0.f;
+#pragma unroll
+              for (int j = 0; j < RB; ++j)
+                if (j == posb - lanebits) part = pass ? qq[j] : qs[j];
+              mine = T_ - 2.f * part;
+            }
+            const float wv = qc_wave_sum_to_lane63(mine);
+            if (lane == 63) s_red[wave][b] = wv;
+          }
+          __syncthreads();
+          if (tid < n) {
+            float s = 0.f;
+            for (int w = 0; w < NW; ++w) s += s_red[w][tid];
+            const int ch8 = pass ? 6 + (c - 2) : c;
+            A.xpart[(((size_t)ch8 * A.pt_stride + pt) * ntau + tau) * H2_XW + tid] = s;
+          }
+          __syncthreads();
+        }
+        if (A.keep_final) {
+          Cplx* g = chi_of(c);
+#pragma unroll
+          for (int q = 0; q < R; ++q) g[abase | dep(tid + NT * q)] = fin[q];
+        }
+      } else {
+        Cplx* g = chi_of(c);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int l = tid + NT * q;
+          g[abase | dep(l)] = t0[h2_swz<RB>(l)];
+        }
+      }
+      __syncthreads();
+    } else {
+      if (!A.first) {
+        Cplx* g = chi_of(c);
+        Cplx* gl = lam_of(c);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int l = tid + NT * q;
+          const int64_t a = abase | dep(l);
+          g[a] = t0[h2_swz<RB>(l)];
+          gl[a] = t1[h2_swz<RB>(l)];
+          if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        // un-embed lam on the local wires (RX^dagger with this point's angles), then keep the amplitudes of weight <= 3
+        for (int grp = 0; grp < nloc / RB; ++grp) {
+          int lbase = 0;
+          {
+            int tb = tid;
+            for (int pos = 0; pos < nloc; ++pos)
+              if (pos / RB != grp) {
+                lbase |= (tb & 1) << pos;
+                tb >>= 1;
+              }
+          }
+          SV<RB> v[1];
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const Cplx y = t1[h2_swz<RB>(lbase | (q << (grp * RB)))];
+            v[0].re[q] = y.re;
+            v[0].im[q] = y.im;
+          }
+#pragma unroll
+          for (int j = 0; j < RB; ++j) {
+            const float* w8 = wdp + (size_t)(n - 1 - sd.lb[grp * RB + j]) * 8;
+            QcGate gg;
+            gg.op = QC_RX;
+            gg.ba = j;
+            gg.bb = -1;
+            gg.slot = 0;
+            qc_apply_gate<RB, 1, true>(v, gg, h2_unif(w8[0]), h2_unif(w8[1]), A.umat);
+          }
+#pragma unroll
+          for (int q = 0; q < R; ++q) t1[h2_swz<RB>(lbase | (q << (grp * RB)))] = {v[0].re[q], v[0].im[q]};
+          __syncthreads();
+        }
+        Cplx* xo = A.xi + (((size_t)c * A.pt_stride + pt) * ntau + tau) * A.nx;
+        for (int j = tid; j < A.nx; j += NT) xo[j] = t1[h2_swz<RB>(A.sparse_idx[j])];
+      }
+      __syncthreads();
+    }
+  }
+
+  if constexpr (BWD) {
+    // in-round gate gradients of this block
+    for (int i = tid; i < sd.np; i += NT) {
+      float s = 0.f;
+      for (int w = 0; w < NW; ++w) s += s_g[w][i];
+      A.gpart[(size_t)i * nblk + blk] = s;
+    }
+    // diagonal tables: Walsh-Hadamard transform of t over the local bits, coefficients of weight <= 2
+    float* tf = reinterpret_cast<float*>(smem_raw);
+    for (int k = 0; k < sd.ntab; ++k) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < R; ++q) tf[h2_swz<RB>(tid + NT * q)] = k == 0 ? tacc0[q] : tacc1[q];
+      __syncthreads();
+      for (int grp = 0; grp < nloc / RB; ++grp) {
+        int lbase = 0;
+        {
+          int tb = tid;
+          for (int pos = 0; pos < nloc; ++pos)
+            if (pos / RB != grp) {
+              lbase |= (tb & 1) << pos;
+              tb >>= 1;
+            }
+        }
+        float u[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) u[q] = tf[h2_swz<RB>(lbase | (q << (grp * RB)))];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+#pragma unroll
+          for (int q = 0; q < R; ++q)
+            if (!((q >> j) & 1)) {
+              const float a = u[q], b = u[q | (1 << j)];
+              u[q] = a + b;
+              u[q | (1 << j)] = a - b;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < R; ++q) tf[h2_swz<RB>(lbase | (q << (grp * RB)))] = u[q];
+        __syncthreads();
+      }
+      for (int j = tid; j < A.nc; j += NT) A.dpart[((size_t)k * nblk + blk) * A.nc + j] = tf[h2_swz<RB>(A.wht_idx[j])];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- small folds
+// qjets[c][w][p] = sum_tau xpart[c][pt][tau][n-1-w]  (+ the 2<chi_k|Z|chi_k> sums for c = 4, 5)
+template <int NCH>
+__global__ void __launch_bounds__(256) k_h2_expval_fold(const float* __restrict__ xpart, int64_t pt_stride, int ntau, int n,
+                                                        int64_t B, int64_t p_first, int64_t npts, float* __restrict__ qjets) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)NCH * npts * n) return;
+  const int w = (int)(i % n);
+  const int64_t pt = (i / n) % npts;
+  const int c = (int)(i / ((int64_t)n * npts));
+  float s = 0.f;
+  for (int q = 0; q < ntau; ++q) s += xpart[(((size_t)c * pt_stride + pt) * ntau + q) * H2_XW + (n - 1 - w)];
+  if (NCH == 6 && c >= 4)
+    for (int q = 0; q < ntau; ++q) s += xpart[(((size_t)(c + 2) * pt_stride + pt) * ntau + q) * H2_XW + (n - 1 - w)];
+  qjets[((int64_t)c * n + w) * B + p_first + pt] = s;
+}
+
+// theta-gradient columns of the tile rows: cleared, then every contribution writes its own slots
+__global__ void k_h2_zero_rows(float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t ntiles, int n_params) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntiles * n_params) return;
+  part[(row0 + i / n_params) * part_stride + i % n_params] = 0.f;
+}
+
+// in-round gates: part[row0 + tile][slot_i] += sum over the tile's (t, tau) blocks of gpart[i][.]
+__global__ void __launch_bounds__(256) k_h2_fold_gates(const float* __restrict__ gpart, int64_t nblk, int per_tile,
+                                                       const int* __restrict__ slots, float* __restrict__ part,
+                                                       int64_t part_stride, int64_t row0) {
+  __shared__ float s_red[4];
+  const int i = blockIdx.x;
+  const int64_t tile = blockIdx.y;
+  const float* src = gpart + (size_t)i * nblk + tile * per_tile;
+  float t = 0.f;
+  for (int b = threadIdx.x; b < per_tile; b += 256) t += src[b];
+  const float w = qc_wave_sum(t);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(row0 + tile) * part_stride + slots[i]] += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// diagonal tables: per tile row, sum the blocks' Walsh-Hadamard coefficients over the 64 points (per tau), then every
+// gate of the table takes its combination.  With s_b(k) = (-1)^{bit_b(k)}:
+//   RZ(b):        dtheta = sum_k s_b t_k
+//   CRZ(c -> b):  dtheta = sum_k [bit_c = 1] s_b t_k = (sum s_b t - sum s_c s_b t) / 2
+// and sum_k s_m t_k over a tile = (+-) W[mask of the local bits of m], the sign from the tile's non-local bits.
+__global__ void __launch_bounds__(256) k_h2_fold_diag(const float* __restrict__ dpart, int64_t nblk, int ntau, int nc,
+                                                      H2Stage sd, const H2DiagGate* __restrict__ dg, int ng,
+                                                      float* __restrict__ part, int64_t part_stride, int64_t row0) {
+  extern __shared__ float s_w[];   // [ntau][nc]
+  const int64_t tile = blockIdx.x;
+  for (int i = threadIdx.x; i < ntau * nc; i += 256) {
+    const int tau = i / nc, j = i % nc;
+    float s = 0.f;
+    for (int t = 0; t < 64; ++t) s += dpart[(((size_t)tile * 64 + t) * ntau + tau) * nc + j];
+    s_w[i] = s;
+  }
+  __syncthreads();
+  const int nloc = sd.nloc;
+  auto posof = [&](int b) {
+    for (int j = 0; j < nloc; ++j)
+      if (sd.lb[j] == b) return j;
+    return -1;
+  };
+  auto gidx = [&](int b) {
+    for (int j = 0; j < sd.ngb; ++j)
+      if (sd.gb[j] == b) return j;
+    return 0;
+  };
+  // coefficient index of a local mask of weight <= 2: 0 | 1 + p | 1 + nloc + pair rank (p < q, p outer)
+  auto cidx = [&](int p, int q) {
+    if (p < 0) return 0;
+    if (q < 0) return 1 + p;
+    if (p > q) { const int x = p; p = q; q = x; }
+    return 1 + nloc + p * nloc - p * (p + 1) / 2 + (q - p - 1);
+  };
+  for (int g = threadIdx.x; g < ng; g += 256) {
+    const H2DiagGate d = dg[g];
+    const int pt_ = posof(d.bt), pc_ = d.bc >= 0 ? posof(d.bc) : -1;
+    float acc = 0.f;
+    for (int tau = 0; tau < ntau; ++tau) {
+      const float* W = s_w + (size_t)tau * nc;
+      const float st = pt_ >= 0 ? 1.f : (((tau >> gidx(d.bt)) & 1) ? -1.f : 1.f);
+      const float a = st * W[cidx(pt_, -1)];
+      if (d.bc < 0) {
+        acc += a;
+      } else {
+        const float sc = pc_ >= 0 ? 1.f : (((tau >> gidx(d.bc)) & 1) ? -1.f : 1.f);
+        const float b = st * sc * W[pt_ >= 0 && pc_ >= 0 ? cidx(pt_, pc_) : (pt_ >= 0 ? cidx(pt_, -1) : (pc_ >= 0 ? cidx(pc_, -1) : 0))];
+        acc += 0.5f * (a - b);
+      }
+    }
+    part[(row0 + tile) * part_stride + d.slot] += acc;
+  }
+}
+
+// cotangents of the angle jets from the un-embedded, sparse lam of every channel (block = one point)
+template <int NCH>
+__global__ void __launch_bounds__(128) k_h2_abar(const Cplx* __restrict__ xi, Cplx* __restrict__ xwork, int64_t pt_stride,
+                                                 int ntau, int nx, H2Stage sd, int n, const float* __restrict__ wd,
+                                                 const int* __restrict__ rank, int64_t B, int64_t p_first,
+                                                 int64_t npts, float* __restrict__ abar, int use_lds) {
+  extern __shared__ Cplx s_x[];          // [ntau][nx] when it fits, else the block works in xwork (global)
+  __shared__ float s_buf[NCH][3][24];
+  const int64_t pt = blockIdx.x;
+  const int64_t p = p_first + pt;
+  const int tid = threadIdx.x;
+  const float* wdp = wd + (size_t)pt * n * 8;
+  const int nloc = sd.nloc;
+  for (int c = 0; c < NCH; ++c) {
+    const Cplx* src = xi + ((size_t)c * pt_stride + pt) * ntau * nx;
+    Cplx* X = use_lds ? s_x : xwork + (size_t)pt * ntau * nx;
+    for (int i = tid; i < ntau * nx; i += 128) X[i] = src[i];
+    __syncthreads();
+    // RX^dagger on the wires of the non-local bits: butterflies across tau
+    for (int j = 0; j < sd.ngb; ++j) {
+      const float* w8 = wdp + (size_t)(n - 1 - sd.gb[j]) * 8;
+      const float cw = w8[0], sw = w8[1];
+      for (int i = tid; i < (ntau >> 1) * nx; i += 128) {
+        const int h = i / nx, e = i % nx;
+        const int t0_ = ((h >> j) << (j + 1)) | (h & ((1 << j) - 1)), t1_ = t0_ | (1 << j);
+        const Cplx a = X[(size_t)t0_ * nx + e], b = X[(size_t)t1_ * nx + e];
+        // RX^dagger = [[c, i s], [i s, c]]
+        X[(size_t)t0_ * nx + e] = {cw * a.re - sw * b.im, cw * a.im + sw * b.re};
+        X[(size_t)t1_ * nx + e] = {cw * b.re - sw * a.im, cw * b.im + sw * a.re};
+      }
+      __syncthreads();
+    }
+    // mu[k] for a full index k of weight <= 3
+    auto mu = [&](int64_t k) {
+      int l = 0, g = 0;
+      for (int j = 0; j < nloc; ++j)
+        if ((k >> sd.lb[j]) & 1) l |= 1 << j;
+      for (int j = 0; j < sd.ngb; ++j)
+        if ((k >> sd.gb[j]) & 1) g |= 1 << j;
+      return X[(size_t)g * nx + rank[l]];
+    };
+    auto E = [&](int w) { return (int64_t)1 << (n - 1 - w); };
+    if (tid < n) {
+      const int w = tid;
+      const int dsel = c == 0 ? 0 : (c <= 3 ? c - 1 : c - 3);
+      auto da = [&](int v) { return wdp[(size_t)v * 8 + 2 + dsel]; };
+      auto dda = [&](int v) { return wdp[(size_t)v * 8 + 5 + (c - 4)]; };
+      const float ip0 = -mu(E(w)).im;
+      float ip1 = 0.f, ip2 = 0.f;
+      if (c >= 1) {
+        float acc = da(w) * mu(0).re;
+        for (int v = 0; v < n; ++v)
+          if (v != w) acc = fmaf(da(v), mu(E(w) | E(v)).re, acc);
+        ip1 = -0.5f * acc;
+      }
+      if (c >= 4) {
+        float S = 0.f;
+        for (int v = 0; v < n; ++v) S = fmaf(da(v), da(v), S);
+        float a = S * mu(E(w)).im;
+        float b = dda(w) * mu(0).re;
+        for (int u = 0; u < n; ++u) {
+          if (u != w) b = fmaf(dda(u), mu(E(w) | E(u)).re, b);
+          for (int v = u + 1; v < n; ++v) a = fmaf(2.f * da(u) * da(v), mu(E(u) ^ E(v) ^ E(w)).im, a);
+        }
+        ip2 = 0.25f * a - 0.5f * b;
+      }
+      // slots as in the register family's tail (qc_circuit_reg_kernels.h): [0] own-order term, [1], [2] lower orders
+      if (c == 0) {
+        s_buf[c][0][w] = ip0;
+      } else if (c <= 3) {
+        s_buf[c][0][w] = ip1;
+        s_buf[c][1][w] = ip0;
+      } else {
+        s_buf[c][0][w] = ip2;
+        s_buf[c][1][w] = 2.f * ip1;
+        s_buf[c][2][w] = ip0;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < n) {
+    const int w = tid;
+    if constexpr (NCH == 6) {
+      abar[((int64_t)0 * n + w) * B + p] = ((s_buf[0][0][w] + s_buf[1][0][w]) + (s_buf[2][0][w] + s_buf[3][0][w])) + (s_buf[4][0][w] + s_buf[5][0][w]);
+      abar[((int64_t)1 * n + w) * B + p] = s_buf[1][1][w];
+      abar[((int64_t)2 * n + w) * B + p] = s_buf[2][1][w] + s_buf[4][1][w];
+      abar[((int64_t)3 * n + w) * B + p] = s_buf[3][1][w] + s_buf[5][1][w];
+      abar[((int64_t)4 * n + w) * B + p] = s_buf[4][2][w];
+      abar[((int64_t)5 * n + w) * B + p] = s_buf[5][2][w];
+    } else {
+      abar[(int64_t)w * B + p] = s_buf[0][0][w];
+    }
+  }
+}
+
+// folded RX layer: d L / d theta_w = sum over the tile's points of d L / d a_w (value-channel row w of abar)
+__global__ void __launch_bounds__(64) k_h2_absorb_grad(const float* __restrict__ abar, int64_t B, int64_t p_first,
+                                                       const QcGate* __restrict__ prog, float* __restrict__ part,
+                                                       int64_t part_stride, int64_t row0) {
+  const int w = blockIdx.x;
+  const int64_t tile = blockIdx.y;
+  const int64_t p = p_first + tile * 64 + threadIdx.x;
+  float v = p < B ? abar[(int64_t)w * B + p] : 0.f;
+  v = qc_wave_sum_to_lane63(v);
+  if (threadIdx.x == 63) part[(row0 + tile) * part_stride + prog[w].slot] += v;
+}
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct H2Ws {
+  Cplx* store;
+  float* wd;
+  Cplx* tabs;
+  float* xpart;
+  float* gpart;
+  float* dpart;
+  Cplx* xi;
+  Cplx* xwork;
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ host side
+struct QcH2 {
+  H2Dev dev;
+};
+
+static int h2_max_np(const H2Plan& P) {
+  int m = 0;
+  for (const H2Stage& s : P.stages) m = s.np > m ? s.np : m;
+  return m;
+}
+static int h2_max_ntau(const H2Plan& P) {
+  int m = 1;
+  for (const H2Stage& s : P.stages) m = (1 << s.ngb) > m ? (1 << s.ngb) : m;
+  return m;
+}
+
+void* qc_h2_create(const qc_program* pg, int absorb) {
+  QcH2* h = new QcH2();
+  H2Dev& D = h->dev;
+  static const int rb12 = [] { const char* e = getenv("QC_H2_RB"); return (e && e[0] == '3') ? 3 : 4; }();
+  D.plan = h2_make_plan(pg->h_gates, pg->n_gates, pg->n_qubits, absorb, rb12);
+  const H2Plan& P = D.plan;
+  const int nl0 = P.stages[0].nloc;
+  std::vector<int> rank((size_t)1 << nl0, -1);
+  for (size_t j = 0; j < P.sparse_idx.size(); ++j) rank[P.sparse_idx[j]] = (int)j;
+  D.nx = (int)P.sparse_idx.size();
+  // coefficient masks in the order k_h2_fold_diag indexes them (nloc = the largest over the stages; stages share T)
+  std::vector<int> wht;
+  {
+    const int nl = nl0;   // every stage has the same nloc (= min(n, T))
+    wht.push_back(0);
+    for (int p = 0; p < nl; ++p) wht.push_back(1 << p);
+    for (int p = 0; p < nl; ++p)
+      for (int q = p + 1; q < nl; ++q) wht.push_back((1 << p) | (1 << q));
+  }
+  D.nc = (int)wht.size();
+  std::vector<int> pslots;
+  D.pslot_off.push_back(0);
+  for (const H2Stage& s : P.stages) {
+    std::vector<int> sl(s.np, 0);
+    for (int r = s.r0; r < s.r0 + s.nr; ++r)
+      if (P.rounds[r].kind == H2_ROUND_GATES)
+        for (int g = P.rounds[r].g0; g < P.rounds[r].g0 + P.rounds[r].ng; ++g)
+          if (P.gates[g].pidx >= 0) sl[P.gates[g].pidx] = P.gates[g].slot;
+    pslots.insert(pslots.end(), sl.begin(), sl.end());
+    D.pslot_off.push_back((int)pslots.size());
+  }
+  bool ok = true;
+  auto up = [&](const void* src, size_t bytes, void** dst) {
+    if (bytes == 0) { *dst = nullptr; return; }
+    ok = ok && hipMalloc(dst, bytes) == hipSuccess;
+    ok = ok && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+  };
+  up(P.rounds.data(), sizeof(H2Round) * P.rounds.size(), (void**)&D.d_rounds);
+  up(P.gates.data(), sizeof(H2Gate) * P.gates.size(), (void**)&D.d_gates);
+  up(P.dgates.data(), sizeof(H2DiagGate) * P.dgates.size(), (void**)&D.d_dgates);
+  up(P.sparse_idx.data(), sizeof(int) * P.sparse_idx.size(), (void**)&D.d_sparse);
+  up(rank.data(), sizeof(int) * rank.size(), (void**)&D.d_rank);
+  up(wht.data(), sizeof(int) * wht.size(), (void**)&D.d_whtidx);
+  up(pslots.data(), sizeof(int) * pslots.size(), (void**)&D.d_pslots);
+  if (!ok) {
+    qc_h2_destroy(h);
+    return nullptr;
+  }
+  return h;
+}
+
+void qc_h2_destroy(void* hp) {
+  if (!hp) return;
+  QcH2* h = (QcH2*)hp;
+  H2Dev& D = h->dev;
+  void* ptrs[] = {D.d_rounds, D.d_gates, D.d_dgates, D.d_sparse, D.d_rank, D.d_whtidx, D.d_pslots};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+int qc_h2_describe_gates(const QcGate* gates, int n_gates, int n_qubits, int absorb, int32_t* out, int cap) {
+  const std::vector<int> d = h2_describe(h2_make_plan(gates, n_gates, n_qubits, absorb));
+  if (out)
+    for (int i = 0; i < cap && i < (int)d.size(); ++i) out[i] = d[i];
+  return (int)d.size();
+}
+
+// bytes that do not depend on the number of resident tiles, and bytes per resident 64-point tile
+static size_t h2_fixed_bytes(const qc_program* pg, const H2Dev& D) {
+  const size_t N = (size_t)1 << pg->n_qubits;
+  return al(sizeof(Cplx) * D.plan.tables.size() * N + 256);
+}
+static size_t h2_tile_bytes(const qc_program* pg, const H2Dev& D, int nch, bool backward) {
+  const size_t N = (size_t)1 << pg->n_qubits;
+  const size_t ntau = h2_max_ntau(D.plan);
+  size_t b = al(sizeof(Cplx) * (backward ? 2 : 1) * nch * 64 * N);               // slot
+  b += al(sizeof(float) * 64 * pg->n_qubits * 8);                                // wd
+  b += al(sizeof(float) * 8 * 64 * ntau * H2_XW);                                // xpart
+  if (backward) {
+    b += al(sizeof(float) * (size_t)(h2_max_np(D.plan) + 1) * 64 * ntau);        // gpart
+    b += al(sizeof(float) * H2_MAXTAB * 64 * ntau * D.nc);                       // dpart
+    b += al(sizeof(Cplx) * (size_t)nch * 64 * ntau * D.nx);                      // xi
+    b += al(sizeof(Cplx) * 64 * ntau * D.nx);                                    // xwork
+  }
+  return b;
+}
+
+size_t qc_h2_bytes(const qc_program* pg, void* hp, int nch, bool backward, int64_t tiles) {
+  const H2Dev& D = ((QcH2*)hp)->dev;
+  return h2_fixed_bytes(pg, D) + (size_t)tiles * h2_tile_bytes(pg, D, nch, backward);
+}
+int64_t qc_h2_tiles_that_fit(const qc_program* pg, void* hp, int nch, bool backward, size_t ws_bytes) {
+  const H2Dev& D = ((QcH2*)hp)->dev;
+  const size_t f = h2_fixed_bytes(pg, D);
+  if (ws_bytes <= f) return 0;
+  return (int64_t)((ws_bytes - f) / h2_tile_bytes(pg, D, nch, backward));
+}
+
+static H2Ws h2_carve(const qc_program* pg, const H2Dev& D, int nch, bool backward, int64_t G, void* ws) {
+  const size_t N = (size_t)1 << pg->n_qubits;
+  const size_t ntau = h2_max_ntau(D.plan);
+  char* p = (char*)ws;
+  H2Ws w = {};
+  w.tabs = (Cplx*)p; p += al(sizeof(Cplx) * D.plan.tables.size() * N + 256);
+  w.wd = (float*)p; p += (size_t)G * al(sizeof(float) * 64 * pg->n_qubits * 8);
+  w.store = (Cplx*)p; p += (size_t)G * al(sizeof(Cplx) * (backward ? 2 : 1) * nch * 64 * N);
+  w.xpart = (float*)p; p += (size_t)G * al(sizeof(float) * 8 * 64 * ntau * H2_XW);
+  if (backward) {
+    w.gpart = (float*)p; p += (size_t)G * al(sizeof(float) * (size_t)(h2_max_np(D.plan) + 1) * 64 * ntau);
+    w.dpart = (float*)p; p += (size_t)G * al(sizeof(float) * H2_MAXTAB * 64 * ntau * D.nc);
+    w.xi = (Cplx*)p; p += (size_t)G * al(sizeof(Cplx) * (size_t)nch * 64 * ntau * D.nx);
+    w.xwork = (Cplx*)p;
+  }
+  return w;
+}
+
+template <int RB, int NCH, int MODE>
+static void h2_launch_stage(const H2Args& A, int64_t npts64, hipStream_t st) {
+  const int nloc = A.sd.nloc;
+  const int NT = (1 << nloc) >> RB;
+  const size_t sh = sizeof(Cplx) * ((size_t)1 << nloc) * (MODE == 1 ? 2 : 1);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_stage<RB, NCH, MODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr = true;
+  }
+  const unsigned grid = (unsigned)(npts64 << A.sd.ngb);
+  hipLaunchKernelGGL((k_h2_stage<RB, NCH, MODE>), dim3(grid), dim3(NT), sh, st, A);
+}
+template <int NCH, int MODE>
+static void h2_launch_stage_rb(int rb, const H2Args& A, int64_t npts64, hipStream_t st) {
+  if (rb == 4) h2_launch_stage<4, NCH, MODE>(A, npts64, st);
+  else if (rb == 3) h2_launch_stage<3, NCH, MODE>(A, npts64, st);
+  else h2_launch_stage<2, NCH, MODE>(A, npts64, st);
+}
+
+// One group of resident tiles [p_first, p_first + npts): forward and / or backward.
+template <int NCH>
+static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, const float* umat, const H2Ws& w, int64_t B,
+                     int64_t p_first, int64_t npts, bool do_fwd, bool keep_final, const float* ajets, float* qjets,
+                     const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, hipStream_t st) {
+  const H2Plan& P = D.plan;
+  const int n = pg->n_qubits;
+  const size_t N = (size_t)1 << n;
+  const int64_t ntiles = qc_ceil_div(npts, 64);
+  const int64_t npts64 = ntiles * 64;
+  const bool backward = qbar != nullptr;
+  H2Args A = {};
+  A.store = w.store;
+  A.slot_elems = (int64_t)((backward || keep_final ? 2 : 1) * NCH * 64 * N);
+  A.B = B;
+  A.p_first = p_first;
+  A.pt_stride = npts64;
+  A.n = n;
+  A.rounds = D.d_rounds;
+  A.gates = D.d_gates;
+  A.trig = trig;
+  A.umat = umat;
+  A.tabs = w.tabs;
+  A.wd = w.wd;
+  A.xpart = w.xpart;
+  A.qbar = qbar;
+  A.gpart = w.gpart;
+  A.dpart = w.dpart;
+  A.xi = w.xi;
+  A.sparse_idx = D.d_sparse;
+  A.wht_idx = D.d_whtidx;
+  A.nx = D.nx;
+  A.nc = D.nc;
+  const int S = (int)P.stages.size();
+  if (do_fwd) {
+    hipLaunchKernelGGL((k_h2_wiredata<NCH>), dim3(qc_ceil_div(npts * n, 256)), dim3(256), 0, st, ajets, B, p_first, npts, n, w.wd, trig,
+                       P.absorb);
+    for (int i = 0; i < S; ++i) {
+      A.sd = P.stages[i];
+      A.first = i == 0;
+      A.last = i == S - 1;
+      A.keep_final = keep_final ? 1 : 0;
+      h2_launch_stage_rb<NCH, 0>(P.rbits, A, npts64, st);
+    }
+    if (qjets) {
+      const int ntau = 1 << P.stages[S - 1].ngb;
+      hipLaunchKernelGGL((k_h2_expval_fold<NCH>), dim3(qc_ceil_div((int64_t)NCH * npts * n, 256)), dim3(256), 0, st, w.xpart,
+                         npts64, ntau, n, B, p_first, npts, qjets);
+    }
+  }
+  if (!backward) return;
+  const int np_all = pg->n_params > 0 ? pg->n_params : 1;
+  hipLaunchKernelGGL(k_h2_zero_rows, dim3(qc_ceil_div(ntiles * np_all, 256)), dim3(256), 0, st, part, part_stride, row0, ntiles,
+                     pg->n_params);
+  for (int i = S - 1; i >= 0; --i) {
+    A.sd = P.stages[i];
+    A.first = i == 0;
+    A.last = i == S - 1;
+    h2_launch_stage_rb<NCH, 1>(P.rbits, A, npts64, st);
+    const int ntau = 1 << A.sd.ngb;
+    if (A.sd.np > 0)
+      hipLaunchKernelGGL(k_h2_fold_gates, dim3(A.sd.np, (unsigned)ntiles), dim3(256), 0, st, w.gpart, npts64 * ntau, 64 * ntau,
+                         D.d_pslots + D.pslot_off[i], part, part_stride, row0);
+    for (int k = 0; k < A.sd.ntab; ++k) {
+      const H2Table& tb = P.tables[A.sd.tab[k]];
+      hipLaunchKernelGGL(k_h2_fold_diag, dim3((unsigned)ntiles), dim3(256), sizeof(float) * ntau * D.nc, st,
+                         w.dpart + (size_t)k * npts64 * ntau * D.nc, npts64 * ntau, ntau, D.nc, A.sd, D.d_dgates + tb.g0, tb.ng, part,
+                         part_stride, row0);
+    }
+  }
+  {
+    const H2Stage& s0 = P.stages[0];
+    const int ntau = 1 << s0.ngb;
+    const size_t xb = sizeof(Cplx) * (size_t)ntau * D.nx;
+    const int use_lds = xb <= 64 * 1024 ? 1 : 0;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_abar<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      attr = true;
+    }
+    hipLaunchKernelGGL((k_h2_abar<NCH>), dim3((unsigned)npts), dim3(128), use_lds ? xb : 0, st, w.xi, w.xwork, npts64, ntau, D.nx, s0,
+                       n, w.wd, D.d_rank, B, p_first, npts, abar, use_lds);
+    if (P.absorb)
+      hipLaunchKernelGGL(k_h2_absorb_grad, dim3(n, (unsigned)ntiles), dim3(64), 0, st, abar, B, p_first, pg->d_gates, part,
+                         part_stride, row0);
+  }
+}
+
+// Forward and / or backward over B points with the workspace `ws`.  `resident`: the caller ran the forward pass of
+// the SAME batch into the same workspace with keep = true and everything fitted -> the backward pass starts from it.
+template <int NCH>
+static int h2_run(const qc_program* pg, void* hp, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
+                  const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, void* ws,
+                  size_t ws_bytes, bool keep, bool resident, hipStream_t st) {
+  const H2Dev& D = ((QcH2*)hp)->dev;
+  const bool backward = qbar != nullptr;
+  const bool two = backward || keep;
+  const int64_t ntiles = qc_ceil_div(B, 64);
+  int64_t G = qc_h2_tiles_that_fit(pg, hp, NCH, two, ws_bytes);
+  if (!ws || G < 1) return QC_ERR_ARG;
+  if (G > ntiles) G = ntiles;
+  if (resident && G < ntiles) return QC_ERR_ARG;
+  const H2Ws w = h2_carve(pg, D, NCH, two, G, ws);
+  const int n = pg->n_qubits;
+  const size_t N = (size_t)1 << n;
+  if (!resident) {
+    for (size_t k = 0; k < D.plan.tables.size(); ++k)
+      hipLaunchKernelGGL(k_h2_diag_table, dim3(qc_ceil_div((int64_t)N, 256)), dim3(256), 0, st, D.d_dgates + D.plan.tables[k].g0,
+                         D.plan.tables[k].ng, trig, n, w.tabs + k * N);
+  }
+  for (int64_t t0 = 0; t0 < ntiles; t0 += G) {
+    const int64_t p_first = t0 * 64;
+    const int64_t npts = (B - p_first) < G * 64 ? (B - p_first) : G * 64;
+    h2_group<NCH>(pg, D, trig, umat, w, B, p_first, npts, !resident, backward || keep, ajets, qjets, qbar, abar, part,
+                  part_stride, row0 + t0, st);
+  }
+  return QC_OK;
+}
+
+int qc_h2_forward(const qc_program* pg, void* hp, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
+                  int64_t B, int nch, void* ws, size_t ws_bytes, bool keep, hipStream_t st) {
+  if (nch == 6) return h2_run<6>(pg, hp, trig, umat, ajets, qjets, nullptr, nullptr, nullptr, 0, 0, B, ws, ws_bytes, keep, false, st);
+  return h2_run<1>(pg, hp, trig, umat, ajets, qjets, nullptr, nullptr, nullptr, 0, 0, B, ws, ws_bytes, keep, false, st);
+}
+int qc_h2_backward(const qc_program* pg, void* hp, const QcTrig* trig, const float* umat, const float* ajets, const float* qbar,
+                   float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, void* ws, size_t ws_bytes,
+                   bool resident, hipStream_t st) {
+  if (nch == 6)
+    return h2_run<6>(pg, hp, trig, umat, ajets, nullptr, qbar, abar, part, part_stride, row0, B, ws, ws_bytes, false, resident, st);
+  return h2_run<1>(pg, hp, trig, umat, ajets, nullptr, qbar, abar, part, part_stride, row0, B, ws, ws_bytes, false, resident, st);
+}

@@ -125,5 +125,16 @@ int qc_hbm_forward(const qc_program* pg, const QcTrig* trig, const float* umat, 
 int qc_hbm_backward(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, const float* qbar,
                     float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, void* ws,
                     size_t ws_bytes, hipStream_t);
+// second-generation HBM family (qc_circuit_hbm2.hip): all tiles of a batch resident when the workspace allows
+void* qc_h2_create(const qc_program* pg, int absorb);
+void qc_h2_destroy(void* h2);
+int qc_h2_describe_gates(const QcGate* gates, int n_gates, int n_qubits, int absorb, int32_t* out, int cap);   // host only
+size_t qc_h2_bytes(const qc_program* pg, void* h2, int nch, bool backward, int64_t tiles);
+int64_t qc_h2_tiles_that_fit(const qc_program* pg, void* h2, int nch, bool backward, size_t ws_bytes);
+int qc_h2_forward(const qc_program* pg, void* h2, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
+                  int64_t B, int nch, void* ws, size_t ws_bytes, bool keep, hipStream_t st);
+int qc_h2_backward(const qc_program* pg, void* h2, const QcTrig* trig, const float* umat, const float* ajets, const float* qbar,
+                   float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, void* ws, size_t ws_bytes,
+                   bool resident, hipStream_t st);
 int qc_amp_fwd_launch(const float* a, float* u, int n, int64_t B, int nch, hipStream_t);
 int qc_amp_bwd_launch(const float* a, const float* ub, float* ab, int n, int64_t B, int nch, hipStream_t);

@@ -85,8 +85,10 @@ class Circuit:
             pass
 
     # -- scratch for the HBM-resident family (n >= 9); empty for the register / lane families
-    def workspace(self, nch: int, backward: bool):
-        need = int(self.lib.qc_circuit_workspace_bytes(self.handle, nch, 1 if backward else 0))
+    def workspace(self, nch: int, backward: bool, B: int = 64):
+        # the whole batch resident when it fits (fewer, larger launches), never less than the one-tile minimum
+        need = max(int(self.lib.qc_circuit_workspace_bytes(self.handle, nch, 1 if backward else 0)),
+                   int(self.lib.qc_circuit_workspace_bytes_batch(self.handle, nch, 1 if backward else 0, B)))
         if need == 0:
             return None, 0
         ws = getattr(self, "_ws", None)
@@ -119,7 +121,7 @@ class Circuit:
             a = self._amp_fwd(a, 1)
         B = a.shape[1]
         out = torch.empty_like(a)
-        wp, wb = self.workspace(1, False)
+        wp, wb = self.workspace(1, False, B)
         L.check(self.lib.qc_forward_expval(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
                                            out.data_ptr(), B, wp, wb, _stream(self.device)), "qc_forward_expval")
         return out
@@ -135,7 +137,7 @@ class Circuit:
         part = torch.empty(rows, P, dtype=torch.float32, device=self.device)
         d_angles = torch.empty_like(a)
         st = _stream(self.device)
-        wp, wb = self.workspace(1, True)
+        wp, wb = self.workspace(1, True, B)
         L.check(self.lib.qc_backward_expval(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
                                             g.data_ptr(), d_angles.data_ptr(), part.data_ptr(), P, 0, B, wp, wb, st),
                 "qc_backward_expval")
@@ -151,7 +153,7 @@ class Circuit:
             a = self._amp_fwd(a, NCH)
         B = a.shape[2]
         out = torch.empty_like(a)
-        wp, wb = self.workspace(NCH, False)
+        wp, wb = self.workspace(NCH, False, B)
         L.check(self.lib.qc_forward_jets(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
                                          out.data_ptr(), B, wp, wb, _stream(self.device)), "qc_forward_jets")
         return out
@@ -167,7 +169,7 @@ class Circuit:
         part = torch.empty(rows, P, dtype=torch.float32, device=self.device)
         abar = torch.empty_like(a)
         st = _stream(self.device)
-        wp, wb = self.workspace(NCH, True)
+        wp, wb = self.workspace(NCH, True, B)
         L.check(self.lib.qc_backward_jets(self.handle, self.trig.data_ptr(), _ptr(self.umat), a.data_ptr(),
                                           g.data_ptr(), abar.data_ptr(), part.data_ptr(), P, 0, B, wp, wb, st),
                 "qc_backward_jets")
@@ -260,7 +262,7 @@ class SolverEngine:
         abar = torch.empty_like(ajets)
         th = part.data_ptr() + 4 * self.theta_off
         c = self.circuit
-        wp, wb = c.workspace(nch, True)
+        wp, wb = c.workspace(nch, True, B)
         cin = c._amp_fwd(ajets, nch) if c.amplitude else ajets
         if nch == 1:
             L.check(self.lib.qc_backward_expval(c.handle, c.trig.data_ptr(), _ptr(c.umat), cin.data_ptr(),

@@ -1,0 +1,99 @@
+"""HBM-resident kernel family (9 <= n <= 20 qubits), round-structured plan (csrc/qc_circuit_hbm2.hip): parity
+against the CPU oracle on programs whose plan has several stages, several tiles per statevector, predicated
+controls, phase-multiply gates, tables with gradients from Walsh-Hadamard coefficients, more than one 64-point
+tile per launch, and a workspace too small to keep the batch resident.  Tolerances as tests/test_gpu_circuit.py
+(1e-5 on <Z>, north_star)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from test_gpu_circuit import TOL_Z, _circuit
+
+from oracle import jets as ojets
+from oracle import statevector as sv
+
+pytestmark = pytest.mark.gpu
+
+VJP_CASES = [("cross_mesh", 12, 1, 1, 70), ("cascade", 14, 1, 1, 66), ("layered", 13, 1, 1, 3), ("sim_circ_15", 11, 1, 1, 5),
+             ("farhi", 10, 1, 1, 9), ("alternate", 9, 1, 1, 130), ("layered", 12, 2, 1, 2), ("cross_mesh", 9, 1, 1, 65)]
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", VJP_CASES)
+def test_value_channel_and_vjp_match_oracle(ans, n, L, seed, B, gpu_device):
+    g = torch.Generator().manual_seed(11 + n + B)
+    circuits = pkg("circuits")
+    P = circuits.params_per_layer(ans, n)
+    params = torch.randn(L, P, generator=g) * 0.8
+    x = torch.randn(B, n, generator=g) * 1.1
+    cot = torch.randn(n, B, generator=g)
+    circ, haar = _circuit(ans, n, L, seed, gpu_device)
+    xo = x.double().requires_grad_(True)
+    po = params.double().requires_grad_(True)
+    q = sv.circuit_expvals(xo, po, ans, n, haar)
+    (q * cot.double()).sum().backward()
+    circ.prepare(params.to(gpu_device))
+    ang = x.t().contiguous().to(gpu_device)
+    qh = circ.forward_expval(ang)
+    assert (qh.cpu().double() - q.detach()).abs().max() < TOL_Z
+    d_ang, d_theta = circ.backward_expval(ang, cot.to(gpu_device))
+    assert (d_ang.t().cpu().double() - xo.grad).abs().max() < 2e-5
+    scale = max(1.0, po.grad.abs().max().item())
+    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 1e-5 * scale * np.sqrt(B)
+    # a workspace that holds ONE tile: the same batch in ceil(B / 64) launches, forward recomputed in the adjoint pass
+    lib = circ.lib
+    one = int(lib.qc_circuit_workspace_bytes(circ.handle, 1, 1))
+    ws = torch.empty(one, dtype=torch.uint8, device=gpu_device)
+    L_ = pkg("hip.lib")
+    st = torch.cuda.current_stream(gpu_device).cuda_stream
+    rows = (B + 63) // 64
+    part = torch.zeros(rows, max(circ.n_params, 1), device=gpu_device)
+    d2 = torch.empty_like(ang)
+    L_.check(lib.qc_backward_expval(circ.handle, circ.trig.data_ptr(), None if circ.umat is None else circ.umat.data_ptr(),
+                                    ang.data_ptr(), cot.to(gpu_device).data_ptr(), d2.data_ptr(), part.data_ptr(),
+                                    part.shape[1], 0, B, ws.data_ptr(), one, st))
+    assert torch.equal(d2, d_ang)                              # same kernels, same order: bit-identical
+    assert (part.sum(0)[: circ.n_params].cpu().double() - po.grad.reshape(-1)).abs().max() < 1e-5 * scale * np.sqrt(B)
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", [("cross_mesh", 10, 1, 1, 2), ("cascade", 11, 1, 1, 1), ("layered", 9, 2, 1, 2)])
+def test_six_channels_and_cotangents_match_oracle(ans, n, L, seed, B, gpu_device):
+    g = torch.Generator().manual_seed(77 + n + B)
+    circuits = pkg("circuits")
+    P = circuits.params_per_layer(ans, n)
+    params = torch.randn(L, P, generator=g) * 0.8
+    ajets = torch.randn(6, n, B, generator=g) * 0.9
+    w = torch.randn(6, n, B, generator=g)
+    circ, haar = _circuit(ans, n, L, seed, gpu_device)
+    ao = ajets.double().requires_grad_(True)
+    po = params.double().requires_grad_(True)
+    qo = ojets.qjets_from_ajets(ao, po, ans, n, haar)
+    (qo * w.double()).sum().backward()
+    circ.prepare(params.to(gpu_device))
+    aj = ajets.to(gpu_device)
+    qh = circ.forward_jets(aj)
+    err = (qh.cpu().double() - qo.detach()).abs()
+    assert err[0].max() < TOL_Z
+    assert err.max() < 1e-5 * max(1.0, qo.detach().abs().max().item())
+    abar, d_theta = circ.backward_jets(aj, w.to(gpu_device))
+    sa = max(1.0, ao.grad.abs().max().item())
+    assert (abar.cpu().double() - ao.grad).abs().max() < 2e-5 * sa
+    st = max(1.0, po.grad.abs().max().item())
+    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 2e-5 * st
+
+
+@pytest.mark.parametrize("env", [{"QC_H2_RB": "3"}, {"QC_HBM_V1": "1"}, {"QC_NO_ABSORB": "1"}])
+def test_plan_variants_pass_the_same_checks(env):
+    """QC_H2_RB=3: eight amplitudes per thread, 512 threads (read once at load, hence the child process);
+    QC_HBM_V1=1: the round-1 kernels (one LDS round trip per gate); QC_NO_ABSORB=1: leading RX layer kept as gates."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "value_channel and (cross_mesh-12 or cascade-14 or layered-13 or alternate-9)"
+    files = [os.path.join(here, "test_gpu_hbm2.py")]
+    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k", sel], env=dict(os.environ, **env),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "4 passed" in r.stdout

@@ -69,9 +69,13 @@ def test_kept_state_gradient_equals_recompute_gradient(tag, over, gpu_device, tm
     recomputed = tr.fs.flat_grad.clone()
     scale = max(1.0, kept.abs().max().item())
     diff = (kept - recomputed).abs().max().item()
-    assert diff <= 2e-6 * scale, diff
-    if n >= 6:      # same kernels either way (store -> load of the same fp32 values): bit-identical
+    if n >= 9:
+        # HBM family: the adjoint pass runs the SAME kernels on the same fp32 values either way -> bit-identical
         assert torch.equal(kept, recomputed), diff
+    else:
+        # register / lane families: the recompute is inlined into the adjoint kernel, where the compiler contracts
+        # multiply-adds differently from the forward kernel that filled the store -> last-bit differences only
+        assert diff <= 1e-7 * scale, diff
 
 
 @pytest.mark.parametrize("tag,over", KEPT_CASES[:2])
