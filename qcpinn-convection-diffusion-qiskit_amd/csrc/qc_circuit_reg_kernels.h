@@ -689,6 +689,186 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_jets_bwd(const QcGate* __r
   k_jets_bwd_body<PG, LOAD>(blockIdx.x, prog, trig, umat, n_gates, n_params, ajets, qbar, abar, part, part_stride, row0, B, chi_store, amp);
 }
 
+// ---- the fused step's adjoint sweep, second form: block = 3 waves on one 64-point tile, wave = TWO channels
+// handled one after the other ({t, value}, {x, xx}, {y, yy}).  Against the six-wave form above:
+//   * 5 blocks per CU (15 waves at <= 128 VGPRs) hold the whole grid of BASELINE config 2 (1 024 residual + 228
+//     value blocks <= 1 280 slots) in ONE round instead of 2.2 rounds of 512;
+//   * no straggler: every wave forms its share D_a chi_a + D_b chi_b of the value channel's cotangent from the two
+//     final states it loads anyway and leaves it in LDS; the value channel's wave adds the three shares when its
+//     turn comes (second in its wave), instead of 160 extra global loads and five extra D-vector builds up front;
+//   * 2 block barriers instead of 3, per-gate wave reductions accumulate over both channels in registers of the
+//     same wave, cross-wave traffic in the tail shrinks to the one row that sums over all channels.
+template <class PG>
+__device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig,
+                                                   const float* __restrict__ umat, int n_gates, int n_params,
+                                                   const float* __restrict__ ajets, const float* __restrict__ qbar,
+                                                   float* __restrict__ abar, float* __restrict__ part,
+                                                   int64_t part_stride, int64_t row0, int64_t B,
+                                                   const float* __restrict__ chi_store, int amp) {
+  constexpr int N = PG::N;
+  constexpr int A2 = 2 << N;
+  constexpr int NA = 1 << N;
+  extern __shared__ float smem[];
+  float* s_l0 = smem;                          // [3 waves][A2][64]: shares of lam_0
+  float* s_t0 = s_l0 + 3 * A2 * 64;            // [2][N][64]: waves 1, 2: their channels' terms of abar[0]
+  float* s_cs = s_t0 + 2 * N * 64;             // [cos | sin][N][64] of the embedding half-angles
+  float* s_acc = s_cs + 2 * N * 64;            // [3 waves][n_params]
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t p = (int64_t)bid * 64 + lane;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+  for (int i = threadIdx.x; i < 3 * n_params; i += 192) s_acc[i] = 0.f;
+  // wires wv, wv + 3, ... of the embedding half-angles
+  for (int w = wv; w < N; w += 3) qc_wire_sincos(s_cs[w * 64 + lane], s_cs[(N + w) * 64 + lane], ajets, B, pc, w, trig, amp >> 1);
+  const int cha = wv == 0 ? 1 : wv + 1;        // first channel of this wave: t, x, y
+  const int chb = wv == 0 ? 0 : wv + 3;        // second: value, xx, yy
+
+  auto load_chi = [&](SV<N>& v, int c) {
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      v.re[k] = chi_store[qc_chi_index<A2>(c, 2 * k, pc)];
+      v.im[k] = chi_store[qc_chi_index<A2>(c, 2 * k + 1, pc)];
+    }
+  };
+  auto dvec = [&](int c, float (&d)[NA]) {
+    float qb[N];
+#pragma unroll
+    for (int w = 0; w < N; ++w) qb[w] = live ? qbar[((int64_t)c * N + w) * B + pc] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < N; ++w) s += ((k >> (N - 1 - w)) & 1) ? -qb[w] : qb[w];
+      d[k] = s;
+    }
+  };
+
+  SV<N> cl[2];
+  float d[NA];
+  {
+    // this wave's share of lam_0 = sum_c D_c chi_c (to LDS), and lam of its first channel; the second channel's final
+    // state and chi_0 stream through (they are reloaded when their turn comes) to keep the live set at two vectors
+    float da_[NA];
+    float* mine = s_l0 + wv * A2 * 64;
+    load_chi(cl[0], cha);
+    dvec(cha, da_);
+    dvec(chb, d);
+    if (wv == 0) {            // second channel = the value channel: lam_t = D_t chi_0
+      load_chi(cl[1], 0);
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        mine[(2 * k) * 64 + lane] = fmaf(da_[k], cl[0].re[k], d[k] * cl[1].re[k]);
+        mine[(2 * k + 1) * 64 + lane] = fmaf(da_[k], cl[0].im[k], d[k] * cl[1].im[k]);
+        cl[1].re[k] *= da_[k];
+        cl[1].im[k] *= da_[k];
+      }
+    } else {                  // lam_x = D_x chi_0 + 2 D_xx chi_x (the same for y)
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const float br = chi_store[qc_chi_index<A2>(chb, 2 * k, pc)], bi = chi_store[qc_chi_index<A2>(chb, 2 * k + 1, pc)];
+        mine[(2 * k) * 64 + lane] = fmaf(da_[k], cl[0].re[k], d[k] * br);
+        mine[(2 * k + 1) * 64 + lane] = fmaf(da_[k], cl[0].im[k], d[k] * bi);
+      }
+#pragma unroll
+      for (int k = 0; k < NA; ++k) {
+        const float x0r = chi_store[qc_chi_index<A2>(0, 2 * k, pc)], x0i = chi_store[qc_chi_index<A2>(0, 2 * k + 1, pc)];
+        cl[1].re[k] = fmaf(2.f * d[k], cl[0].re[k], da_[k] * x0r);
+        cl[1].im[k] = fmaf(2.f * d[k], cl[0].im[k], da_[k] * x0i);
+      }
+    }
+  }
+  __syncthreads();   // shares of lam_0, s_cs, s_acc
+
+  float t_own[N];    // this wave's channels' terms of abar[0] (against their own embedded state)
+  float t_a1[N];     // first channel, against phi: abar[cha]'s first term
+#pragma unroll
+  for (int w = 0; w < N; ++w) t_own[w] = t_a1[w] = 0.f;
+  const float* aj = qc_launder(ajets);
+
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    const int ch = half == 0 ? cha : chb;
+    if (half == 1) {
+      load_chi(cl[0], chb);
+      if (wv == 0) {          // lam_0: the three shares
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+          cl[1].re[k] = (s_l0[(2 * k) * 64 + lane] + s_l0[(A2 + 2 * k) * 64 + lane]) + s_l0[(2 * A2 + 2 * k) * 64 + lane];
+          cl[1].im[k] = (s_l0[(2 * k + 1) * 64 + lane] + s_l0[(A2 + 2 * k + 1) * 64 + lane]) + s_l0[(2 * A2 + 2 * k + 1) * 64 + lane];
+        }
+      } else {                // lam_xx = D_xx chi_0
+        dvec(chb, d);
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+          cl[1].re[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k, pc)];
+          cl[1].im[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k + 1, pc)];
+        }
+      }
+    }
+    PG::bwd(cl, prog, trig, umat, n_gates, s_acc + wv * n_params, lane, amp >> 1);
+
+    // cotangents of the angle jets in the frame pulled back through the embedding (qc_gates.h)
+    float ca[N], sa[N], da[N], dda[N];
+    load_sincos<N>(ca, sa, aj, B, pc, trig, amp >> 1, s_cs);
+    qc_unembed<N>(cl[1], ca, sa);
+    const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+      da[w] = ch >= 1 ? aj[((int64_t)dirch * N + w) * B + pc] : 0.f;
+      dda[w] = ch >= 4 ? aj[((int64_t)ch * N + w) * B + pc] : 0.f;
+    }
+    float T[N];
+    if (ch == 0) {
+      qc_pull_ip0<N>(T, cl[1]);
+#pragma unroll
+      for (int w = 0; w < N; ++w) t_own[w] += T[w];
+    } else if (ch <= 3) {
+      qc_pull_ip1<N>(T, cl[1], da);
+#pragma unroll
+      for (int w = 0; w < N; ++w) t_own[w] += T[w];
+      qc_pull_ip0<N>(T, cl[1]);
+#pragma unroll
+      for (int w = 0; w < N; ++w) t_a1[w] = T[w];
+    } else {
+      qc_pull_ip2<N>(T, cl[1], da, dda);
+#pragma unroll
+      for (int w = 0; w < N; ++w) t_own[w] += T[w];
+      qc_pull_ip1<N>(T, cl[1], da);
+#pragma unroll
+      for (int w = 0; w < N; ++w) t_a1[w] = fmaf(2.f, T[w], t_a1[w]);   // abar[x] = ip0(mu_x) + 2 ip1(mu_xx)
+      qc_pull_ip0<N>(T, cl[1]);
+      if (live) {
+#pragma unroll
+        for (int w = 0; w < N; ++w) abar[((int64_t)ch * N + w) * B + p] = T[w];   // abar[xx] = ip0(mu_xx)
+      }
+    }
+  }
+  if (live) {
+#pragma unroll
+    for (int w = 0; w < N; ++w) abar[((int64_t)cha * N + w) * B + p] = t_a1[w];
+  }
+  if (wv != 0) {
+#pragma unroll
+    for (int w = 0; w < N; ++w) s_t0[((wv - 1) * N + w) * 64 + lane] = t_own[w];
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int w = 0; w < N; ++w) {
+      const float r = (t_own[w] + s_t0[w * 64 + lane]) + s_t0[(N + w) * 64 + lane];
+      if (live) abar[(int64_t)w * B + p] = r;
+      if (amp >> 1) {   // folded RX layer: d L / d theta_w = sum over points of d L / d angle_w
+        const float tot = qc_wave_sum_to_lane63(live ? r : 0.f);
+        if (lane == 63) s_acc[prog[w].slot] += tot;
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_params; i += 192)
+    part[(row0 + bid) * part_stride + i] = (s_acc[i] + s_acc[n_params + i]) + s_acc[2 * n_params + i];
+}
+
 // ---- residual + value tiles in one launch (see qc_mlp.hip): blocks [0, n_val) run the value-channel kernel on
 // 6 x 64 boundary / initial points, the rest the six-channel kernel on a 64-point residual tile
 template <class PG>
@@ -712,6 +892,21 @@ __global__ void __launch_bounds__(384, QC_JB_WAVES) k_circ_bwd_both(
                               chi_store, amp);
   else
     k_value_bwd_body<PG, 6>(blockIdx.x, prog, trig, umat, n_gates, n_params, angles, cot, d_angles, part, part_stride,
+                            row0_v, Bv, amp);
+}
+
+// the same stage with 3-wave blocks (k_jets_bwd2_body); angle encoding only (the merged step's precondition)
+template <class PG>
+__global__ void __launch_bounds__(192, 4) k_circ_bwd_both2(
+    const QcGate* __restrict__ prog, const QcTrig* __restrict__ trig, const float* __restrict__ umat, int n_gates, int n_params,
+    const float* __restrict__ ajets, const float* __restrict__ qbar, float* __restrict__ abar, int64_t row0_r, int64_t Br,
+    const float* __restrict__ chi_store, const float* __restrict__ angles, const float* __restrict__ cot,
+    float* __restrict__ d_angles, int64_t row0_v, int64_t Bv, float* __restrict__ part, int64_t part_stride, int amp, int n_val) {
+  if ((int)blockIdx.x >= n_val)
+    k_jets_bwd2_body<PG>(blockIdx.x - n_val, prog, trig, umat, n_gates, n_params, ajets, qbar, abar, part, part_stride, row0_r, Br,
+                         chi_store, amp);
+  else
+    k_value_bwd_body<PG, 3>(blockIdx.x, prog, trig, umat, n_gates, n_params, angles, cot, d_angles, part, part_stride,
                             row0_v, Bv, amp);
 }
 
@@ -794,6 +989,15 @@ struct RegLaunch {
                            const float* qbar, float* abar, int64_t row0_r, int64_t Br, const float* chi_store,
                            const float* angles, const float* cot, float* d_angles, int64_t row0_v, int64_t Bv, float* part,
                            int64_t part_stride, hipStream_t st) {
+    static const bool six = [] { const char* e = getenv("QC_BWD6"); return e && e[0] == '1'; }();   // A/B: the six-wave form
+    if (!six && !pg->amplitude) {
+      const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 192);
+      const size_t sh = ((size_t)3 * (2u << PG::N) * 64 + (size_t)4 * PG::N * 64 + (size_t)3 * pg->n_params) * sizeof(float);
+      hipLaunchKernelGGL(k_circ_bwd_both2<PG>, dim3(nr + nv), dim3(192), sh, st, pg->d_gates, trig, umat, pg->n_gates,
+                         pg->n_params, ajets, qbar, abar, row0_r, Br, chi_store, angles, cot, d_angles, row0_v, Bv, part,
+                         part_stride, qc_embed_flags(pg), nv);
+      return QC_OK;
+    }
     const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 384);
     const size_t sh = ((size_t)6 * 3 * PG::N * 64 + (size_t)6 * pg->n_params + 2 * PG::N * 64) * sizeof(float);   // >= the value blocks' 6 rows
     hipLaunchKernelGGL(k_circ_bwd_both<PG>, dim3(nr + nv), dim3(384), sh, st, pg->d_gates, trig, umat, pg->n_gates,
