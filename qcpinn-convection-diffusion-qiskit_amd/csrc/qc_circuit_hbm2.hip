@@ -148,6 +148,10 @@ __device__ __forceinline__ H2Round h2_load_round(const H2Round* p) {
   r.ng = h2_uni(p->ng);
   r.table = h2_uni(p->table);
   r.tslot = h2_uni(p->tslot);
+  r.tab_pre = h2_uni(p->tab_pre);
+  r.ts_pre = h2_uni(p->ts_pre);
+  r.tab_post = h2_uni(p->tab_post);
+  r.ts_post = h2_uni(p->ts_post);
   return r;
 }
 __device__ __forceinline__ H2Gate h2_load_gate(const H2Gate* p) {
@@ -209,13 +213,26 @@ __device__ __forceinline__ void h2_apply_u4(SV<N> (&v)[K], int hq, int lq, const
 }
 
 // MODE 0: forward.  MODE 1: backward (chi and lam).  RB register bits per round, NT = 2^(nloc - RB) threads.
-template <int RB, int NCH, int MODE>
+//
+// Amplitude mappings.  LINEAR: thread tid owns local indices tid | (q << LBITS), q < 2^RB (coalesced HBM access).
+// ROUND: thread owns lbase | roff[q], lbase = tid spread over the positions outside the round's register set.  The LDS
+// swizzle and the local -> global index deposit are GF(2)-linear / OR-linear over disjoint bit sets, so every
+// address is (per-thread part, once per phase) XOR / OR (per-q part, wave-uniform scalars).
+// A stage whose first executed round keeps the low four local positions as lane bits takes its input straight from
+// HBM (or generates it) in that round's mapping, and the last one stores straight to HBM: a one-round stage touches
+// LDS only for reductions.
+// ROLE (what the stage may need, so that dead per-thread state costs no registers): bit 0 = may be the plan's last
+// stage (forward: value-channel tile for the <Z> sums; backward: lam_0 accumulator), bit 1 = may carry diagonal tables
+// (backward: t accumulators).
+template <int RB, int NCH, int MODE, int ROLE>
 __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_stage(const H2Args A) {
   constexpr bool BWD = MODE == 1;
+  constexpr bool LASTC = (ROLE & 1) != 0, TABC = (ROLE & 2) != 0;
   constexpr int R = 1 << RB;
+  constexpr int KV = BWD ? 2 : 1;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   const H2Stage& sd = A.sd;
-  const int nloc = sd.nloc, TS = 1 << nloc, NT = TS >> RB;
+  const int nloc = sd.nloc, TS = 1 << nloc, NT = TS >> RB, LBITS = nloc - RB;
   Cplx* t0 = reinterpret_cast<Cplx*>(smem_raw);          // chi tile
   Cplx* t1 = t0 + (BWD ? TS : 0);                        // lam tile (backward)
   __shared__ int s_depA[64], s_depB[64];                 // local index -> global offset, low / high 6 positions
@@ -246,10 +263,9 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
     }
     return;
   }
-  // global offset of the tile and of a local index
-  int64_t abase = 0;
+  int abase = 0;   // global index of the tile (amplitude indices fit 32 bits: n <= 20)
   for (int j = 0; j < sd.ngb; ++j)
-    if ((tau >> j) & 1) abase |= (int64_t)1 << sd.gb[j];
+    if ((tau >> j) & 1) abase |= 1 << sd.gb[j];
   if (tid < 64) {
     int a = 0, b = 0;
     for (int j = 0; j < 6 && j < nloc; ++j)
@@ -262,27 +278,45 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
   if constexpr (BWD) {
     for (int i = tid; i < 8 * H2_MAXP; i += NT) (&s_g[0][0])[i] = 0.f;
   }
-  auto dep = [&](int l) { return (int64_t)(s_depA[l & 63] | s_depB[l >> 6]); };
+  auto dep = [&](int l) { return s_depA[l & 63] | s_depB[l >> 6]; };
+  // The thread index as an opaque value: addresses derived from it are recomputed where they are used instead of
+  // being hoisted out of the channel loop and held in ~100 VGPRs for the whole kernel.
+  auto ftid = [&]() {
+    int v = tid;
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   const float* wdp = A.wd + (size_t)pt * n * 8;
   Cplx* slot = A.store + (size_t)tile64 * A.slot_elems;
   auto chi_of = [&](int c) { return slot + ((size_t)c * 64 + t) * N; };
   auto lam_of = [&](int c) { return slot + ((size_t)(NCH + c) * 64 + t) * N; };
 
-  // registers that live across the channel loop
-  Cplx x0[BWD ? 1 : R];       // forward, last stage: final value-channel tile
-  Cplx l0acc[BWD ? R : 1];    // backward, last stage: lam_0 = sum_c D_c chi_c
-  float tacc0[BWD ? R : 1], tacc1[BWD ? R : 1];   // backward: t = sum_c Im(conj lam chi) at the stage's tables
-  if constexpr (BWD) {
+  // linear mapping, per-q parts (wave-uniform)
+  int lin_sw[R], lin_dep[R];
 #pragma unroll
-    for (int q = 0; q < R; ++q) {
-      l0acc[q] = {0.f, 0.f};
-      tacc0[q] = 0.f;
-      tacc1[q] = 0.f;
-    }
+  for (int q = 0; q < R; ++q) {
+    lin_sw[q] = h2_swz<RB>(q << LBITS);
+    int d = 0;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) d |= ((q >> j) & 1) << sd.lb[LBITS + j];
+    lin_dep[q] = d;
+  }
+
+  // registers that live across the channel loop
+  Cplx x0[!BWD && LASTC ? R : 1];     // forward, last stage: final value-channel tile
+  Cplx l0acc[BWD && LASTC ? R : 1];   // backward, last stage: lam_0 = sum_c D_c chi_c
+  float tacc0[BWD && TABC ? R : 1];   // backward: t = sum_c Im(conj lam chi) at the stage's table
+  if constexpr (BWD && LASTC) {
+#pragma unroll
+    for (int q = 0; q < R; ++q) l0acc[q] = {0.f, 0.f};
+  }
+  if constexpr (BWD && TABC) {
+#pragma unroll
+    for (int q = 0; q < R; ++q) tacc0[q] = 0.f;
   }
   __syncthreads();
 
-  if constexpr (BWD) {
+  if constexpr (BWD && LASTC) {
     if (A.last) {
       // D_c[k] = sum_w (+-) qbar[c][w][p] by index bit n-1-w: constant part (non-local bits) + two 64-entry tables
       for (int i = tid; i < NCH * 128; i += NT) {
@@ -308,159 +342,299 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
   }
   auto Dval = [&](int c, int l) { return s_Dg[c] + s_D[c][l & 63] + s_D[c][64 + (l >> 6)]; };
 
+  // which rounds talk to HBM directly
+  const bool gen = !BWD && A.first;
+  bool din = false, dout = false;
+  if (sd.nr > 0) {
+    const H2Round* rf = A.rounds + sd.r0 + (BWD ? sd.nr - 1 : 0);
+    const H2Round* rl = A.rounds + sd.r0 + (BWD ? 0 : sd.nr - 1);
+    din = h2_uni(rf->kind) == H2_ROUND_GATES && (gen || h2_uni(rf->rb[0]) >= 4);
+    dout = h2_uni(rl->kind) == H2_ROUND_GATES && h2_uni(rl->rb[0]) >= 4 && !(BWD && A.first);
+  }
+  const bool uses_lds = !(din && dout && sd.nr == 1);
+
+  // forward generation: series factor tables of channel c (non-local bits folded into table A)
+  auto gen_tables = [&](int c) {
+    const int ord = c == 0 ? 0 : (c <= 3 ? 1 : 2);
+    const int dsel = c == 0 ? 0 : (c <= 3 ? c - 1 : c - 3);      // direction: t, x, y
+    const int ddsel = c >= 4 ? c - 4 : 0;
+    auto step = [&](float& P0, float& P1, float& P2, int bit_pos, int bitval) {
+      const float* w8 = wdp + (size_t)(n - 1 - bit_pos) * 8;
+      const float cw = w8[0], sw = w8[1];
+      const float da = ord >= 1 ? w8[2 + dsel] : 0.f, dda = ord >= 2 ? w8[5 + ddsel] : 0.f;
+      const float w0 = bitval ? sw : cw, e = bitval ? cw : -sw;
+      const float w1 = 0.5f * da * e, w2 = 0.5f * dda * e - 0.25f * da * da * w0;
+      const float p0 = P0, p1 = P1, p2 = P2;
+      P0 = p0 * w0;
+      P1 = p0 * w1 + p1 * w0;
+      P2 = p0 * w2 + 2.f * p1 * w1 + p2 * w0;
+    };
+    for (int e_ = tid; e_ < 128; e_ += NT) {
+      const int half = e_ >> 6, v = e_ & 63;
+      float P0 = 1.f, P1 = 0.f, P2 = 0.f;
+      if (half == 0) {
+        for (int j = 0; j < sd.ngb; ++j) step(P0, P1, P2, sd.gb[j], (tau >> j) & 1);
+        for (int j = 0; j < 6 && j < nloc; ++j) step(P0, P1, P2, sd.lb[j], (v >> j) & 1);
+        s_tabA[v][0] = P0; s_tabA[v][1] = P1; s_tabA[v][2] = P2;
+      } else {
+        for (int j = 6; j < nloc; ++j) step(P0, P1, P2, sd.lb[j], (v >> (j - 6)) & 1);
+        s_tabB[v][0] = P0; s_tabB[v][1] = P1; s_tabB[v][2] = P2;
+      }
+    }
+  };
+  auto gen_amp = [&](int c, int l, int a) {   // local index l, global index a
+    const int ord = c == 0 ? 0 : (c <= 3 ? 1 : 2);
+    const float a0 = s_tabA[l & 63][0], a1 = s_tabA[l & 63][1], a2 = s_tabA[l & 63][2];
+    const float b0 = s_tabB[l >> 6][0], b1 = s_tabB[l >> 6][1], b2 = s_tabB[l >> 6][2];
+    const float m = ord == 0 ? a0 * b0 : (ord == 1 ? a1 * b0 + a0 * b1 : a0 * b2 + 2.f * a1 * b1 + a2 * b0);
+    const int ph = __popc((unsigned)a) & 3;
+    Cplx v;
+    v.re = ph == 0 ? m : (ph == 2 ? -m : 0.f);
+    v.im = ph == 1 ? -m : (ph == 3 ? m : 0.f);
+    return v;
+  };
+  // backward, last stage: cotangent of channel c's final state at local index l from (chi_c, chi_0) [DESIGN.md §3]:
+  // lam_0 = sum_c D_c chi_c, lam_t = D_t chi_0, lam_x = D_x chi_0 + 2 D_xx chi_x, lam_xx = D_xx chi_0 (same for y)
+  auto build_lam = [&](int c, int l, Cplx x, Cplx xv, Cplx& acc) {
+    Cplx y;
+    if (c == 0) {
+      const float d = Dval(0, l);
+      y = {acc.re + d * x.re, acc.im + d * x.im};
+    } else {
+      const float d = Dval(c, l);
+      y = {d * xv.re, d * xv.im};
+      if (c == 2 || c == 3) {
+        const float d2 = 2.f * Dval(c + 2, l);
+        y.re += d2 * x.re;
+        y.im += d2 * x.im;
+      }
+      acc.re += d * x.re;
+      acc.im += d * x.im;
+    }
+    return y;
+  };
+  // forward, last stage: <Z> sums of this tile against the value channel's final tile, per index bit.
+  // fin[q] at local index lb_ | (q's bits at positions rbp[]), lb_ = this thread's lane part.
+  auto expval = [&](int c, const Cplx (&fin)[R], int lb_, const int (&rbp)[RB]) {
+    float tot = 0.f, sq = 0.f, qs[RB], qq[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) qs[j] = qq[j] = 0.f;
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      constexpr int XQ = (!BWD && LASTC) ? R : 1;
+      const int xq = q < XQ ? q : 0;
+      if (c == 0) x0[xq] = fin[q];
+      const float w = c == 0 ? fin[q].re * fin[q].re + fin[q].im * fin[q].im
+                             : 2.f * (x0[xq].re * fin[q].re + x0[xq].im * fin[q].im);
+      const float w2 = 2.f * (fin[q].re * fin[q].re + fin[q].im * fin[q].im);
+      tot += w;
+      sq += w2;
+#pragma unroll
+      for (int j = 0; j < RB; ++j)
+        if ((q >> j) & 1) {
+          qs[j] += w;
+          qq[j] += w2;
+        }
+    }
+    for (int pass = 0; pass < ((c == 2 || c == 3) ? 2 : 1); ++pass) {
+      for (int b = 0; b < n; ++b) {   // b = global index bit
+        const int wb = sd.where[b];   // local position, or -(1 + j) for the non-local bit gb[j]
+        const float T_ = pass ? sq : tot;
+        float mine;
+        if (wb < 0) {
+          mine = ((tau >> (-wb - 1)) & 1) ? -T_ : T_;
+        } else {
+          float part = 0.f;
+          bool isreg = false;
+#pragma unroll
+          for (int j = 0; j < RB; ++j)
+            if (wb == rbp[j]) {
+              part = pass ? qq[j] : qs[j];
+              isreg = true;
+            }
+          mine = isreg ? T_ - 2.f * part : (((lb_ >> wb) & 1) ? -T_ : T_);
+        }
+        const float wv = qc_wave_sum_to_lane63(mine);
+        if (lane == 63) s_red[wave][b] = wv;
+      }
+      __syncthreads();
+      if (tid < n) {
+        float s = 0.f;
+        for (int w = 0; w < NW; ++w) s += s_red[w][tid];
+        const int ch8 = pass ? 6 + (c - 2) : c;
+        A.xpart[(((size_t)ch8 * A.pt_stride + pt) * ntau + tau) * H2_XW + tid] = s;
+      }
+      __syncthreads();
+    }
+  };
+  // per-thread part of a round mapping: positions outside the register set rb[] take the bits of the thread index
+  auto round_lbase = [&](const int (&rb)[4]) {
+    bool contig = true;
+#pragma unroll
+    for (int j = 1; j < RB; ++j) contig = contig && rb[j] == rb[0] + j;
+    const int tv = ftid();
+    if (contig) {
+      const int lo = rb[0];
+      return (tv & ((1 << lo) - 1)) | ((tv >> lo) << (lo + RB));
+    }
+    int regmask = 0, lbase = 0, tb = tv;
+#pragma unroll
+    for (int j = 0; j < RB; ++j) regmask |= 1 << rb[j];
+    for (int pos = 0; pos < nloc; ++pos)
+      if (!((regmask >> pos) & 1)) {
+        lbase |= (tb & 1) << pos;
+        tb >>= 1;
+      }
+    return lbase;
+  };
+
   // ------------------------------------------------------------------ channel loop
   for (int ci = 0; ci < NCH; ++ci) {
     // backward: the value channel last (its cotangent needs every other channel's final state)
     const int c = BWD ? (ci + 1 < NCH ? ci + 1 : 0) : ci;
-    // ---------------- load phase (linear mapping: thread tid owns local indices tid + NT q)
-    if constexpr (!BWD) {
-      if (A.first) {
-        // generate channel c of the embedded product state: series (P0, P1, P2) of the tile = G (x) A (x) B
-        const int ord = c == 0 ? 0 : (c <= 3 ? 1 : 2);
-        const int dsel = c == 0 ? 0 : (c <= 3 ? c - 1 : c - 3);      // direction: t, x, y
-        const int ddsel = c >= 4 ? c - 4 : 0;
-        auto step = [&](float& P0, float& P1, float& P2, int bit_pos, int bitval) {
-          const float* w8 = wdp + (size_t)(n - 1 - bit_pos) * 8;
-          const float cw = w8[0], sw = w8[1];
-          const float da = ord >= 1 ? w8[2 + dsel] : 0.f, dda = ord >= 2 ? w8[5 + ddsel] : 0.f;
-          const float w0 = bitval ? sw : cw, e = bitval ? cw : -sw;
-          const float w1 = 0.5f * da * e, w2 = 0.5f * dda * e - 0.25f * da * da * w0;
-          const float p0 = P0, p1 = P1, p2 = P2;
-          P0 = p0 * w0;
-          P1 = p0 * w1 + p1 * w0;
-          P2 = p0 * w2 + 2.f * p1 * w1 + p2 * w0;
-        };
-        for (int e_ = tid; e_ < 128; e_ += NT) {
-          const int half = e_ >> 6, v = e_ & 63;
-          float P0 = 1.f, P1 = 0.f, P2 = 0.f;
-          if (half == 0) {   // the non-local bits are folded into table A
-            for (int j = 0; j < sd.ngb; ++j) step(P0, P1, P2, sd.gb[j], (tau >> j) & 1);
-            for (int j = 0; j < 6 && j < nloc; ++j) step(P0, P1, P2, sd.lb[j], (v >> j) & 1);
-            s_tabA[v][0] = P0; s_tabA[v][1] = P1; s_tabA[v][2] = P2;
-          } else {
-            for (int j = 6; j < nloc; ++j) step(P0, P1, P2, sd.lb[j], (v >> (j - 6)) & 1);
-            s_tabB[v][0] = P0; s_tabB[v][1] = P1; s_tabB[v][2] = P2;
-          }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-          const int l = tid + NT * q;
-          const float a0 = s_tabA[l & 63][0], a1 = s_tabA[l & 63][1], a2 = s_tabA[l & 63][2];
-          const float b0 = s_tabB[l >> 6][0], b1 = s_tabB[l >> 6][1], b2 = s_tabB[l >> 6][2];
-          const float m = ord == 0 ? a0 * b0 : (ord == 1 ? a1 * b0 + a0 * b1 : a0 * b2 + 2.f * a1 * b1 + a2 * b0);
-          const int ph = __popcll((unsigned long long)(abase | dep(l))) & 3;
-          Cplx v;
-          v.re = ph == 0 ? m : (ph == 2 ? -m : 0.f);
-          v.im = ph == 1 ? -m : (ph == 3 ? m : 0.f);
-          t0[h2_swz<RB>(l)] = v;
-        }
-      } else {
+    if (gen) {
+      gen_tables(c);
+      __syncthreads();
+    }
+    // ---------------- load phase through LDS (linear mapping) unless the first round reads HBM itself
+    if (!din) {
+      const int tg = ftid();
+      const int tsw = h2_swz<RB>(tg), tdp = abase | dep(tg);
+      if constexpr (!BWD) {
         const Cplx* g = chi_of(c);
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-          const int l = tid + NT * q;
-          t0[h2_swz<RB>(l)] = g[abase | dep(l)];
+          const int a = tdp | lin_dep[q];
+          t0[tsw ^ lin_sw[q]] = gen ? gen_amp(c, tg | (q << LBITS), a) : g[a];
         }
-      }
-    } else {
-      const Cplx* g = chi_of(c);
-      const Cplx* gl = lam_of(c);
+      } else {
+        const Cplx* g = chi_of(c);
+        const Cplx* gl = lam_of(c);
+        const Cplx* g0 = chi_of(0);
 #pragma unroll
-      for (int q = 0; q < R; ++q) {
-        const int l = tid + NT * q;
-        const int64_t a = abase | dep(l);
-        Cplx x = g[a];
-        Cplx y;
-        if (A.last) {
-          // (the value channel's final tile is re-read per channel: 32 KiB from L2 instead of 32 live registers)
-          const Cplx xv = c == 0 ? x : chi_of(0)[a];
-          // cotangents of the final states: lam_0 = sum_c D_c chi_c, lam_t = D_t chi_0,
-          // lam_x = D_x chi_0 + 2 D_xx chi_x, lam_xx = D_xx chi_0 (same for y)   [DESIGN.md §3]
-          if (c == 0) {
-            const float d = Dval(0, l);
-            y = {l0acc[q].re + d * x.re, l0acc[q].im + d * x.im};
-          } else {
-            const float d = Dval(c, l);
-            y = {d * xv.re, d * xv.im};
-            if (c == 2 || c == 3) {
-              const float d2 = 2.f * Dval(c + 2, l);
-              y.re += d2 * x.re;
-              y.im += d2 * x.im;
-            }
-            l0acc[q].re += d * x.re;
-            l0acc[q].im += d * x.im;
-          }
-        } else {
-          y = gl[a];
+        for (int q = 0; q < R; ++q) {
+          const int a = tdp | lin_dep[q];
+          const Cplx x = g[a];
+          Cplx y;
+          if (LASTC && A.last) y = build_lam(c, tg | (q << LBITS), x, c == 0 ? x : g0[a], l0acc[LASTC ? q : 0]);
+          else y = gl[a];
+          t0[tsw ^ lin_sw[q]] = x;
+          t1[tsw ^ lin_sw[q]] = y;
         }
-        t0[h2_swz<RB>(l)] = x;
-        t1[h2_swz<RB>(l)] = y;
-        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // four loads in flight per array, not sixteen (registers)
       }
+      __syncthreads();
     }
-    __syncthreads();
 
     // ---------------- rounds
     for (int ri = 0; ri < sd.nr; ++ri) {
-      const H2Round rd = h2_load_round(A.rounds + sd.r0 + (BWD ? sd.nr - 1 - ri : ri));
-      if (rd.kind == H2_ROUND_TABLE) {
+      const int rix = BWD ? sd.nr - 1 - ri : ri;
+      const H2Round rd = h2_load_round(A.rounds + sd.r0 + rix);
+      if (rd.kind == H2_ROUND_TABLE) {   // a table without a gate round to ride on: element-wise pass in the linear mapping
         const Cplx* tab = A.tabs + (size_t)rd.table * N;
+        const int tg = ftid();
+        const int tsw = h2_swz<RB>(tg), tdp = abase | dep(tg);
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-          const int l = tid + NT * q;
-          const Cplx ph = tab[abase | dep(l)];
-          const int li = h2_swz<RB>(l);
+          const Cplx ph = tab[tdp | lin_dep[q]];
+          const int li = tsw ^ lin_sw[q];
           if constexpr (!BWD) {
             t0[li] = cmul(t0[li], ph);
           } else {
             const Cplx x = t0[li], y = t1[li];
             const float tv = y.re * x.im - y.im * x.re;   // Im(conj(lam) chi), invariant under the run's gates
-            if (rd.tslot == 0) tacc0[q] += tv;
-            else tacc1[q] += tv;
+            if constexpr (TABC) tacc0[q] += tv;
             t0[li] = cmulc(x, ph);
             t1[li] = cmulc(y, ph);
           }
-          if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         continue;
       }
-      // gate round: register bits rd.rb[], lane bits = the other local positions
-      int regmask = 0;
-#pragma unroll
-      for (int j = 0; j < RB; ++j) regmask |= 1 << rd.rb[j];
-      int lbase = 0;
-      {
-        int tb = tid;
-        for (int pos = 0; pos < nloc; ++pos)
-          if (!((regmask >> pos) & 1)) {
-            lbase |= (tb & 1) << pos;
-            tb >>= 1;
-          }
-      }
-      int roff[R];
+      // gate round: per-thread and per-q parts of the mapping
+      const int lbase = round_lbase(rd.rb);
+      const int sl = h2_swz<RB>(lbase);
+      const int alane = abase | dep(lbase);          // global index of this thread's amplitudes, register bits clear
+      int roff[R], sr[R], dr[R];
 #pragma unroll
       for (int q = 0; q < R; ++q) {
-        int o = 0;
+        int o = 0, d = 0;
 #pragma unroll
-        for (int j = 0; j < RB; ++j) o |= ((q >> j) & 1) << rd.rb[j];
+        for (int j = 0; j < RB; ++j) {
+          o |= ((q >> j) & 1) << rd.rb[j];
+          d |= ((q >> j) & 1) << sd.lb[rd.rb[j]];
+        }
         roff[q] = o;
+        sr[q] = h2_swz<RB>(o);
+        dr[q] = d;
       }
-      SV<RB> v[BWD ? 2 : 1];
+      const bool first_r = ri == 0, last_r = ri == sd.nr - 1;
+      SV<RB> v[KV];
+      if (first_r && din) {
+        if constexpr (!BWD) {
+          const Cplx* g = chi_of(c);
 #pragma unroll
-      for (int q = 0; q < R; ++q) {
-        const int li = h2_swz<RB>(lbase | roff[q]);
-        const Cplx x = t0[li];
-        v[0].re[q] = x.re;
-        v[0].im[q] = x.im;
-        if constexpr (BWD) {
-          const Cplx y = t1[li];
-          v[1].re[q] = y.re;
-          v[1].im[q] = y.im;
+          for (int q = 0; q < R; ++q) {
+            const int a = alane | dr[q];
+            const Cplx x = gen ? gen_amp(c, lbase | roff[q], a) : g[a];
+            v[0].re[q] = x.re;
+            v[0].im[q] = x.im;
+          }
+        } else {
+          const Cplx* g = chi_of(c);
+          const Cplx* gl = lam_of(c);
+          const Cplx* g0 = chi_of(0);
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            const int a = alane | dr[q];
+            const Cplx x = g[a];
+            Cplx y;
+            if (LASTC && A.last) y = build_lam(c, lbase | roff[q], x, c == 0 ? x : g0[a], l0acc[LASTC ? q : 0]);
+            else y = gl[a];
+            v[0].re[q] = x.re;
+            v[0].im[q] = x.im;
+            v[1].re[q] = y.re;
+            v[1].im[q] = y.im;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int li = sl ^ sr[q];
+          const Cplx x = t0[li];
+          v[0].re[q] = x.re;
+          v[0].im[q] = x.im;
+          if constexpr (BWD) {
+            const Cplx y = t1[li];
+            v[1].re[q] = y.re;
+            v[1].im[q] = y.im;
+          }
         }
       }
-      const int64_t alane = abase | dep(lbase);   // global index of this thread's amplitudes, register bits clear
+      // a diagonal table riding on this round: forward before the gates (pre) / after them (post); backward mirrored,
+      // with t = Im(conj(lam) chi) accumulated per amplitude at the table's output side
+      auto table_here = [&](int table, int tslot) {
+        const Cplx* tab = A.tabs + (size_t)table * N;
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const Cplx ph = tab[alane | dr[q]];
+          if constexpr (!BWD) {
+            const Cplx x = cmul({v[0].re[q], v[0].im[q]}, ph);
+            v[0].re[q] = x.re;
+            v[0].im[q] = x.im;
+          } else {
+            const float tv = v[1].re[q] * v[0].im[q] - v[1].im[q] * v[0].re[q];
+            if constexpr (TABC) tacc0[q] += tv;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+              const Cplx x = cmulc({v[k].re[q], v[k].im[q]}, ph);
+              v[k].re[q] = x.re;
+              v[k].im[q] = x.im;
+            }
+          }
+        }
+      };
+      if (!BWD && rd.tab_pre >= 0) table_here(rd.tab_pre, rd.ts_pre);
+      if (BWD && rd.tab_post >= 0) table_here(rd.tab_post, rd.ts_post);
       for (int gi = 0; gi < rd.ng; ++gi) {
         const H2Gate hg = h2_load_gate(A.gates + rd.g0 + (BWD ? rd.ng - 1 - gi : gi));
         float c_ = 1.f, s_ = 0.f;
@@ -480,14 +654,14 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             if constexpr (BWD) {
               if (hg.pidx >= 0) grad = qc_gate_grad<RB>(v[1], v[0], gg);
             }
-            qc_apply_gate<RB, BWD ? 2 : 1, BWD>(v, gg, c_, s_, A.umat);
+            qc_apply_gate<RB, KV, BWD>(v, gg, c_, s_, A.umat);
             break;
           }
           case H2_K_PRED: {
             const bool on = (alane >> hg.cbit) & 1;
             if (on) {
               if (hg.op == QC_CNOT) {
-                h2_apply_x<RB, BWD ? 2 : 1>(v, hg.tq);
+                h2_apply_x<RB, KV>(v, hg.tq);
               } else {   // CRX
                 QcGate gg;
                 gg.op = QC_RX;
@@ -497,7 +671,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
                 if constexpr (BWD) {
                   if (hg.pidx >= 0) grad = qc_gate_grad<RB>(v[1], v[0], gg);
                 }
-                qc_apply_gate<RB, BWD ? 2 : 1, BWD>(v, gg, c_, s_, A.umat);
+                qc_apply_gate<RB, KV, BWD>(v, gg, c_, s_, A.umat);
               }
             }
             break;
@@ -506,7 +680,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             const float sg = BWD ? -s_ : s_;
 #pragma unroll
             for (int q = 0; q < R; ++q) {
-              const int64_t a = alane | dep(roff[q]);
+              const int a = alane | dr[q];
               const bool on = hg.cbit < 0 || ((a >> hg.cbit) & 1);
               const bool hi = (a >> hg.tbit) & 1;
               if constexpr (BWD) {
@@ -515,7 +689,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
               }
               const float sq = on ? (hi ? sg : -sg) : 0.f, cq = on ? c_ : 1.f;   // multiply by cq + i sq
 #pragma unroll
-              for (int k = 0; k < (BWD ? 2 : 1); ++k) {
+              for (int k = 0; k < KV; ++k) {
                 const float ar = v[k].re[q], ai = v[k].im[q];
                 v[k].re[q] = cq * ar - sq * ai;
                 v[k].im[q] = cq * ai + sq * ar;
@@ -528,7 +702,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             const float* um = A.umat + (hg.slot * 2 + (BWD ? 1 : 0)) * 32;
 #pragma unroll
             for (int i = 0; i < 32; ++i) us[i] = h2_unif(um[i]);
-            h2_apply_u4<RB, BWD ? 2 : 1>(v, hg.tq, hg.cq, us);
+            h2_apply_u4<RB, KV>(v, hg.tq, hg.cq, us);
             break;
           }
           default: break;
@@ -540,142 +714,118 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           }
         }
       }
-#pragma unroll
-      for (int q = 0; q < R; ++q) {
-        const int li = h2_swz<RB>(lbase | roff[q]);
-        t0[li] = {v[0].re[q], v[0].im[q]};
-        if constexpr (BWD) t1[li] = {v[1].re[q], v[1].im[q]};
-      }
-      __syncthreads();
-    }
+      if (!BWD && rd.tab_post >= 0) table_here(rd.tab_post, rd.ts_post);
+      if (BWD && rd.tab_pre >= 0) table_here(rd.tab_pre, rd.ts_pre);
 
-    // ---------------- store phase
-    if constexpr (!BWD) {
-      if (A.last) {
-        // <Z> sums of this tile against the value channel's final tile (held in x0), by index bit
-        float tot = 0.f, sq = 0.f, qs[RB], qq[RB];
+      if (last_r && dout) {
+        // straight to HBM in this round's mapping
+        if constexpr (!BWD) {
+          if (LASTC && A.last) {
+            Cplx fin[R];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) qs[j] = qq[j] = 0.f;
-        Cplx fin[R];
+            for (int q = 0; q < R; ++q) fin[q] = {v[0].re[q], v[0].im[q]};
+            int rbp[RB];
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-          fin[q] = t0[h2_swz<RB>(tid + NT * q)];
-          if (c == 0) x0[q] = fin[q];
-          const float w = c == 0 ? fin[q].re * fin[q].re + fin[q].im * fin[q].im
-                                 : 2.f * (x0[q].re * fin[q].re + x0[q].im * fin[q].im);
-          const float w2 = 2.f * (fin[q].re * fin[q].re + fin[q].im * fin[q].im);
-          tot += w;
-          sq += w2;
-#pragma unroll
-          for (int j = 0; j < RB; ++j)
-            if ((q >> j) & 1) {
-              qs[j] += w;
-              qq[j] += w2;
-            }
-        }
-        const int lanebits = nloc - RB;   // local positions [0, lanebits) = thread bits, the rest = q bits
-        for (int pass = 0; pass < ((c == 2 || c == 3) ? 2 : 1); ++pass) {
-          for (int b = 0; b < n; ++b) {   // b = global index bit
-            // where does bit b live?
-            int posb = -1;
-            for (int j = 0; j < nloc; ++j)
-              if (sd.lb[j] == b) posb = j;
-            float mine;
-            const float T_ = pass ? sq : tot;
-            if (posb < 0) {
-              int jb = 0;
-              for (int j = 0; j < sd.ngb; ++j)
-                if (sd.gb[j] == b) jb = j;
-              mine = ((tau >> jb) & 1) ? -T_ : T_;
-            } else if (posb < lanebits) {
-              mine = ((tid >> posb) & 1) ? -T_ : T_;
-            } else {
-              float part = 0.f;
-#pragma unroll
-              for (int j = 0; j < RB; ++j)
-                if (j == posb - lanebits) part = pass ? qq[j] : qs[j];
-              mine = T_ - 2.f * part;
-            }
-            const float wv = qc_wave_sum_to_lane63(mine);
-            if (lane == 63) s_red[wave][b] = wv;
+            for (int j = 0; j < RB; ++j) rbp[j] = rd.rb[j];
+            expval(c, fin, lbase, rbp);
           }
-          __syncthreads();
-          if (tid < n) {
-            float s = 0.f;
-            for (int w = 0; w < NW; ++w) s += s_red[w][tid];
-            const int ch8 = pass ? 6 + (c - 2) : c;
-            A.xpart[(((size_t)ch8 * A.pt_stride + pt) * ntau + tau) * H2_XW + tid] = s;
+          if (!(LASTC && A.last) || A.keep_final) {
+            Cplx* g = chi_of(c);
+#pragma unroll
+            for (int q = 0; q < R; ++q) g[alane | dr[q]] = {v[0].re[q], v[0].im[q]};
           }
-          __syncthreads();
-        }
-        if (A.keep_final) {
+        } else {
           Cplx* g = chi_of(c);
-#pragma unroll
-          for (int q = 0; q < R; ++q) g[abase | dep(tid + NT * q)] = fin[q];
-        }
-      } else {
-        Cplx* g = chi_of(c);
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-          const int l = tid + NT * q;
-          g[abase | dep(l)] = t0[h2_swz<RB>(l)];
-        }
-      }
-      __syncthreads();
-    } else {
-      if (!A.first) {
-        Cplx* g = chi_of(c);
-        Cplx* gl = lam_of(c);
-#pragma unroll
-        for (int q = 0; q < R; ++q) {
-          const int l = tid + NT * q;
-          const int64_t a = abase | dep(l);
-          g[a] = t0[h2_swz<RB>(l)];
-          gl[a] = t1[h2_swz<RB>(l)];
-          if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        // un-embed lam on the local wires (RX^dagger with this point's angles), then keep the amplitudes of weight <= 3
-        for (int grp = 0; grp < nloc / RB; ++grp) {
-          int lbase = 0;
-          {
-            int tb = tid;
-            for (int pos = 0; pos < nloc; ++pos)
-              if (pos / RB != grp) {
-                lbase |= (tb & 1) << pos;
-                tb >>= 1;
-              }
-          }
-          SV<RB> v[1];
+          Cplx* gl = lam_of(c);
 #pragma unroll
           for (int q = 0; q < R; ++q) {
-            const Cplx y = t1[h2_swz<RB>(lbase | (q << (grp * RB)))];
-            v[0].re[q] = y.re;
-            v[0].im[q] = y.im;
+            g[alane | dr[q]] = {v[0].re[q], v[0].im[q]};
+            gl[alane | dr[q]] = {v[1].re[q], v[1].im[q]};
           }
-#pragma unroll
-          for (int j = 0; j < RB; ++j) {
-            const float* w8 = wdp + (size_t)(n - 1 - sd.lb[grp * RB + j]) * 8;
-            QcGate gg;
-            gg.op = QC_RX;
-            gg.ba = j;
-            gg.bb = -1;
-            gg.slot = 0;
-            qc_apply_gate<RB, 1, true>(v, gg, h2_unif(w8[0]), h2_unif(w8[1]), A.umat);
-          }
-#pragma unroll
-          for (int q = 0; q < R; ++q) t1[h2_swz<RB>(lbase | (q << (grp * RB)))] = {v[0].re[q], v[0].im[q]};
-          __syncthreads();
         }
-        Cplx* xo = A.xi + (((size_t)c * A.pt_stride + pt) * ntau + tau) * A.nx;
-        for (int j = tid; j < A.nx; j += NT) xo[j] = t1[h2_swz<RB>(A.sparse_idx[j])];
+      } else {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+          const int li = sl ^ sr[q];
+          t0[li] = {v[0].re[q], v[0].im[q]};
+          if constexpr (BWD) t1[li] = {v[1].re[q], v[1].im[q]};
+        }
+        __syncthreads();
       }
-      __syncthreads();
     }
+
+    // ---------------- store phase through LDS (linear mapping) unless the last round wrote HBM itself
+    if (!dout) {
+      const int tg = ftid();
+      const int tsw = h2_swz<RB>(tg), tdp = abase | dep(tg);
+      if constexpr (!BWD) {
+        if (LASTC && A.last) {
+          Cplx fin[R];
+#pragma unroll
+          for (int q = 0; q < R; ++q) fin[q] = t0[tsw ^ lin_sw[q]];
+          int rbp[RB];
+#pragma unroll
+          for (int j = 0; j < RB; ++j) rbp[j] = LBITS + j;
+          expval(c, fin, tg, rbp);
+          if (A.keep_final) {
+            Cplx* g = chi_of(c);
+#pragma unroll
+            for (int q = 0; q < R; ++q) g[tdp | lin_dep[q]] = fin[q];
+          }
+        } else {
+          Cplx* g = chi_of(c);
+#pragma unroll
+          for (int q = 0; q < R; ++q) g[tdp | lin_dep[q]] = t0[tsw ^ lin_sw[q]];
+        }
+      } else {
+        if (!A.first) {
+          Cplx* g = chi_of(c);
+          Cplx* gl = lam_of(c);
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            g[tdp | lin_dep[q]] = t0[tsw ^ lin_sw[q]];
+            gl[tdp | lin_dep[q]] = t1[tsw ^ lin_sw[q]];
+          }
+        } else {
+          // un-embed lam on the local wires (RX^dagger with this point's angles), then keep the amplitudes of weight <= 3
+          for (int grp = 0; grp < nloc / RB; ++grp) {
+            int rbg[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < RB; ++j) rbg[j] = grp * RB + j;
+            const int lb2 = round_lbase(rbg);
+            const int sl2 = h2_swz<RB>(lb2);
+            SV<RB> u[1];
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+              const Cplx y = t1[sl2 ^ h2_swz<RB>(q << (grp * RB))];
+              u[0].re[q] = y.re;
+              u[0].im[q] = y.im;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+              const float* w8 = wdp + (size_t)(n - 1 - sd.lb[grp * RB + j]) * 8;
+              QcGate gg;
+              gg.op = QC_RX;
+              gg.ba = j;
+              gg.bb = -1;
+              gg.slot = 0;
+              qc_apply_gate<RB, 1, true>(u, gg, h2_unif(w8[0]), h2_unif(w8[1]), A.umat);
+            }
+#pragma unroll
+            for (int q = 0; q < R; ++q) t1[sl2 ^ h2_swz<RB>(q << (grp * RB))] = {u[0].re[q], u[0].im[q]};
+            __syncthreads();
+          }
+          Cplx* xo = A.xi + (((size_t)c * A.pt_stride + pt) * ntau + tau) * A.nx;
+          for (int j = tid; j < A.nx; j += NT) xo[j] = t1[h2_swz<RB>(A.sparse_idx[j])];
+        }
+      }
+    }
+    if (uses_lds || gen) __syncthreads();   // the next channel overwrites the tile / the series tables
   }
 
   if constexpr (BWD) {
     // in-round gate gradients of this block
+    __syncthreads();
     for (int i = tid; i < sd.np; i += NT) {
       float s = 0.f;
       for (int w = 0; w < NW; ++w) s += s_g[w][i];
@@ -683,24 +833,35 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
     }
     // diagonal tables: Walsh-Hadamard transform of t over the local bits, coefficients of weight <= 2
     float* tf = reinterpret_cast<float*>(smem_raw);
-    for (int k = 0; k < sd.ntab; ++k) {
+    for (int k = 0; k < (TABC ? sd.ntab : 0); ++k) {   // (H2_MAXTAB = 1: one accumulator)
       __syncthreads();
+      {
+        // t was accumulated in the mapping of the round the table rides on
+        const H2Round rt = h2_load_round(A.rounds + sd.r0 + sd.tab_round[k]);
+        if (rt.kind == H2_ROUND_TABLE) {
+          const int tsw = h2_swz<RB>(ftid());
 #pragma unroll
-      for (int q = 0; q < R; ++q) tf[h2_swz<RB>(tid + NT * q)] = k == 0 ? tacc0[q] : tacc1[q];
+          for (int q = 0; q < R; ++q) tf[tsw ^ lin_sw[q]] = tacc0[TABC ? q : 0];
+        } else {
+          const int sl = h2_swz<RB>(round_lbase(rt.rb));
+#pragma unroll
+          for (int q = 0; q < R; ++q) {
+            int o = 0;
+#pragma unroll
+            for (int j = 0; j < RB; ++j) o |= ((q >> j) & 1) << rt.rb[j];
+            tf[sl ^ h2_swz<RB>(o)] = tacc0[TABC ? q : 0];
+          }
+        }
+      }
       __syncthreads();
       for (int grp = 0; grp < nloc / RB; ++grp) {
-        int lbase = 0;
-        {
-          int tb = tid;
-          for (int pos = 0; pos < nloc; ++pos)
-            if (pos / RB != grp) {
-              lbase |= (tb & 1) << pos;
-              tb >>= 1;
-            }
-        }
+        int rbg[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < RB; ++j) rbg[j] = grp * RB + j;
+        const int sl2 = h2_swz<RB>(round_lbase(rbg));
         float u[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) u[q] = tf[h2_swz<RB>(lbase | (q << (grp * RB)))];
+        for (int q = 0; q < R; ++q) u[q] = tf[sl2 ^ h2_swz<RB>(q << (grp * RB))];
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
 #pragma unroll
@@ -712,7 +873,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             }
         }
 #pragma unroll
-        for (int q = 0; q < R; ++q) tf[h2_swz<RB>(lbase | (q << (grp * RB)))] = u[q];
+        for (int q = 0; q < R; ++q) tf[sl2 ^ h2_swz<RB>(q << (grp * RB))] = u[q];
         __syncthreads();
       }
       for (int j = tid; j < A.nc; j += NT) A.dpart[((size_t)k * nblk + blk) * A.nc + j] = tf[h2_swz<RB>(A.wht_idx[j])];
@@ -957,7 +1118,9 @@ static int h2_max_ntau(const H2Plan& P) {
 void* qc_h2_create(const qc_program* pg, int absorb) {
   QcH2* h = new QcH2();
   H2Dev& D = h->dev;
-  static const int rb12 = [] { const char* e = getenv("QC_H2_RB"); return (e && e[0] == '3') ? 3 : 4; }();
+  // 12-bit tiles: 8 amplitudes per thread x 512 threads by default (four waves per SIMD without spills in the
+  // backward kernels); QC_H2_RB=4 selects 16 amplitudes x 256 threads (fewer rounds, two waves per SIMD)
+  static const int rb12 = [] { const char* e = getenv("QC_H2_RB"); return (e && e[0] == '4') ? 4 : 3; }();
   D.plan = h2_make_plan(pg->h_gates, pg->n_gates, pg->n_qubits, absorb, rb12);
   const H2Plan& P = D.plan;
   const int nl0 = P.stages[0].nloc;
@@ -1071,25 +1234,43 @@ static H2Ws h2_carve(const qc_program* pg, const H2Dev& D, int nch, bool backwar
   return w;
 }
 
-template <int RB, int NCH, int MODE>
+template <int RB, int NCH, int MODE, int ROLE>
 static void h2_launch_stage(const H2Args& A, int64_t npts64, hipStream_t st) {
   const int nloc = A.sd.nloc;
   const int NT = (1 << nloc) >> RB;
   const size_t sh = sizeof(Cplx) * ((size_t)1 << nloc) * (MODE == 1 ? 2 : 1);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_stage<RB, NCH, MODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_stage<RB, NCH, MODE, ROLE>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr = true;
   }
   const unsigned grid = (unsigned)(npts64 << A.sd.ngb);
-  hipLaunchKernelGGL((k_h2_stage<RB, NCH, MODE>), dim3(grid), dim3(NT), sh, st, A);
+  hipLaunchKernelGGL((k_h2_stage<RB, NCH, MODE, ROLE>), dim3(grid), dim3(NT), sh, st, A);
+}
+// tile bits 12 (RB = 3, 4): one instantiation per role; the small-n tiles (RB = 2, and RB = 3 at n = 9) take the
+// general form
+template <int RB, int NCH, int MODE>
+static void h2_launch_role(const H2Args& A, int64_t npts64, hipStream_t st) {
+  const int role = (A.last ? 1 : 0) | ((MODE == 1 && A.sd.ntab > 0) ? 2 : 0);
+  if (A.sd.nloc < 12) return h2_launch_stage<RB, NCH, MODE, 3>(A, npts64, st);
+  if constexpr (MODE == 0) {
+    if (role & 1) h2_launch_stage<RB, NCH, 0, 1>(A, npts64, st);
+    else h2_launch_stage<RB, NCH, 0, 0>(A, npts64, st);
+  } else {
+    switch (role) {
+      case 0: h2_launch_stage<RB, NCH, 1, 0>(A, npts64, st); break;
+      case 1: h2_launch_stage<RB, NCH, 1, 1>(A, npts64, st); break;
+      case 2: h2_launch_stage<RB, NCH, 1, 2>(A, npts64, st); break;
+      default: h2_launch_stage<RB, NCH, 1, 3>(A, npts64, st); break;
+    }
+  }
 }
 template <int NCH, int MODE>
 static void h2_launch_stage_rb(int rb, const H2Args& A, int64_t npts64, hipStream_t st) {
-  if (rb == 4) h2_launch_stage<4, NCH, MODE>(A, npts64, st);
-  else if (rb == 3) h2_launch_stage<3, NCH, MODE>(A, npts64, st);
-  else h2_launch_stage<2, NCH, MODE>(A, npts64, st);
+  if (rb == 4) h2_launch_role<4, NCH, MODE>(A, npts64, st);
+  else if (rb == 3) h2_launch_role<3, NCH, MODE>(A, npts64, st);
+  else h2_launch_stage<2, NCH, MODE, 3>(A, npts64, st);
 }
 
 // One group of resident tiles [p_first, p_first + npts): forward and / or backward.

@@ -26,8 +26,8 @@
 constexpr int H2_T = 12;        // local bits per tile (32 KiB of complex64)
 constexpr int H2_LOW = 4;       // low bits that are always local
 constexpr int H2_MAXP = 64;     // parametric in-round gates per stage (LDS accumulator rows)
-constexpr int H2_MAXTAB = 2;    // diagonal tables per stage (register accumulators of t)
-constexpr int H2_TABLE_MIN = 8; // shortest diagonal run that becomes a table
+constexpr int H2_MAXTAB = 1;    // diagonal tables per stage (one register accumulator of t per thread)
+constexpr int H2_TABLE_MIN = 24; // shortest diagonal run that becomes a table (shorter runs ride in rounds as phase gates)
 constexpr int H2_MAXRG = 24;    // gates per round (parametric ones need a partial-sum register each: <= 8 of them)
 constexpr int H2_MAXRP = 8;
 
@@ -54,8 +54,11 @@ struct H2Round {
   int nrb;         // register bits of this round (gate rounds)
   int rb[4];       // their LOCAL positions, ascending
   int g0, ng;      // gate range in the plan's gate array
-  int table;       // table rounds: global table index
-  int tslot;       // table rounds: which of the stage's t accumulators it owns
+  int table;       // stand-alone table rounds: global table index
+  int tslot;       // stand-alone table rounds: which of the stage's t accumulators it owns
+  // gate rounds: a diagonal table applied to the amplitudes as they are loaded (pre) / before they are stored (post),
+  // in the round's own register mapping - no LDS round trip of its own; -1 = none
+  int tab_pre, ts_pre, tab_post, ts_post;
 };
 
 struct H2Stage {
@@ -66,6 +69,8 @@ struct H2Stage {
   int np;          // parametric in-round gates
   int ntab;        // table rounds
   int tab[H2_MAXTAB];
+  int tab_round[H2_MAXTAB];   // round (index within the stage) whose amplitude mapping the table's t accumulator uses
+  int where[24];   // index bit b: its local position, or -(1 + j) when it is the non-local bit gb[j]
 };
 
 struct H2DiagGate { int op, bt, bc, gi, slot; };   // diagonal gate of a table, global bit numbering
@@ -243,13 +248,11 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
         if (r.rb[q] == p) return q;
       return -1;
     };
+    int pend_tab = -1, pend_ts = -1;   // a table waiting for the next gate round (becomes its tab_pre)
     for (const Item& it : items) {
       if (it.kind == 1) {
-        H2Round r = {};
-        r.kind = H2_ROUND_TABLE;
-        r.table = (int)P.tables.size();
-        r.tslot = sd.ntab;
-        sd.tab[sd.ntab++] = r.table;
+        const int table = (int)P.tables.size(), tslot = sd.ntab;
+        sd.tab[sd.ntab++] = table;
         H2Table tb = {(int)P.dgates.size(), (int)it.g.size()};
         for (int j : it.g) {
           const QcGate& g = gate(j);
@@ -257,7 +260,17 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
           P.dgates.push_back({g.op, ctl ? g.bb : g.ba, ctl ? g.ba : -1, g_first + j, g.slot});
         }
         P.tables.push_back(tb);
-        P.rounds.push_back(r);
+        if (pend_tab >= 0) {   // two tables in a row cannot happen (diagonal runs merge); keep the plan valid anyway
+          H2Round r = {};
+          r.kind = H2_ROUND_TABLE;
+          r.table = pend_tab;
+          r.tslot = pend_ts;
+          r.tab_pre = r.tab_post = r.ts_pre = r.ts_post = -1;
+          sd.tab_round[pend_ts] = (int)P.rounds.size() - sd.r0;
+          P.rounds.push_back(r);
+        }
+        pend_tab = table;
+        pend_ts = tslot;
         open = false;
         continue;
       }
@@ -308,6 +321,12 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
         r.g0 = (int)P.gates.size();
         r.ng = 0;
         r.table = -1;
+        r.tslot = -1;
+        r.tab_pre = pend_tab;
+        r.ts_pre = pend_ts;
+        r.tab_post = r.ts_post = -1;
+        if (pend_tab >= 0) sd.tab_round[pend_ts] = (int)P.rounds.size() - sd.r0;
+        pend_tab = pend_ts = -1;
         P.rounds.push_back(r);
         open = true;
         open_np = 0;
@@ -339,7 +358,25 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
       P.gates.push_back(hg);
       ++r.ng;
     }
+    if (pend_tab >= 0) {   // the stage ends with a table: after the last gate round, or alone
+      if ((int)P.rounds.size() > sd.r0 && P.rounds.back().kind == H2_ROUND_GATES) {
+        P.rounds.back().tab_post = pend_tab;
+        P.rounds.back().ts_post = pend_ts;
+        sd.tab_round[pend_ts] = (int)P.rounds.size() - 1 - sd.r0;
+      } else {
+        H2Round r = {};
+        r.kind = H2_ROUND_TABLE;
+        r.table = pend_tab;
+        r.tslot = pend_ts;
+        r.tab_pre = r.tab_post = r.ts_pre = r.ts_post = -1;
+        sd.tab_round[pend_ts] = (int)P.rounds.size() - sd.r0;
+        P.rounds.push_back(r);
+      }
+    }
     sd.nr = (int)P.rounds.size() - sd.r0;
+    for (int b = 0; b < 24; ++b) sd.where[b] = 0;
+    for (int j = 0; j < sd.nloc; ++j) sd.where[sd.lb[j]] = j;
+    for (int j = 0; j < sd.ngb; ++j) sd.where[sd.gb[j]] = -(1 + j);
     P.stages.push_back(sd);
     for (int j = 0; j < G; ++j)
       if (state[j] == 1) {
@@ -353,6 +390,8 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
     for (int j = 0; j < T; ++j) sd.lb[j] = j;
     sd.ngb = 0;
     for (int b = T; b < n; ++b) sd.gb[sd.ngb++] = b;
+    for (int j = 0; j < sd.nloc; ++j) sd.where[sd.lb[j]] = j;
+    for (int j = 0; j < sd.ngb; ++j) sd.where[sd.gb[j]] = -(1 + j);
     P.stages.push_back(sd);
   }
   // local indices of weight <= 3 in the first stage's tile (sparse read-out of the un-embedded cotangents)
@@ -383,6 +422,10 @@ inline std::vector<int> h2_describe(const H2Plan& P) {
       for (int q = 0; q < rd.nrb; ++q) o.push_back(rd.rb[q]);
       o.push_back(rd.table);
       o.push_back(rd.tslot);
+      o.push_back(rd.tab_pre);
+      o.push_back(rd.ts_pre);
+      o.push_back(rd.tab_post);
+      o.push_back(rd.ts_post);
       o.push_back(rd.kind == H2_ROUND_GATES ? rd.ng : 0);
       if (rd.kind == H2_ROUND_GATES)
         for (int g = rd.g0; g < rd.g0 + rd.ng; ++g) {

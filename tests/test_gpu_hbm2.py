@@ -86,9 +86,9 @@ def test_six_channels_and_cotangents_match_oracle(ans, n, L, seed, B, gpu_device
     assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 2e-5 * st
 
 
-@pytest.mark.parametrize("env", [{"QC_H2_RB": "3"}, {"QC_HBM_V1": "1"}, {"QC_NO_ABSORB": "1"}])
+@pytest.mark.parametrize("env", [{"QC_H2_RB": "4"}, {"QC_HBM_V1": "1"}, {"QC_NO_ABSORB": "1"}])
 def test_plan_variants_pass_the_same_checks(env):
-    """QC_H2_RB=3: eight amplitudes per thread, 512 threads (read once at load, hence the child process);
+    """QC_H2_RB=4: sixteen amplitudes per thread, 256 threads (read once at load, hence the child process);
     QC_HBM_V1=1: the round-1 kernels (one LDS round trip per gate); QC_NO_ABSORB=1: leading RX layer kept as gates."""
     here = os.path.dirname(os.path.abspath(__file__))
     sel = "value_channel and (cross_mesh-12 or cascade-14 or layered-13 or alternate-9)"

@@ -46,6 +46,7 @@ def parse(d):
             rd = {"kind": nx(), "nrb": nx()}
             rd["rb"] = [nx() for _ in range(rd["nrb"])]
             rd["table"], rd["tslot"] = nx(), nx()
+            rd["tab_pre"], rd["ts_pre"], rd["tab_post"], rd["ts_post"] = nx(), nx(), nx(), nx()
             ng = nx()
             rd["gates"] = []
             for _ in range(ng):
@@ -143,15 +144,24 @@ def test_plan_is_equivalent_to_the_program(ansatz, n, layers):
         assert st["nloc"] % plan["rbits"] == 0
         pos = {b: j for j, b in enumerate(lb)}
         pidx_seen, ntab = [], 0
+        tslots = []
+
+        def run_table(k, ts):
+            tslots.append(ts)
+            for g in plan["tables"][k]:
+                assert g["op"] in (OP_RZ, OP_CRZ) and gates[g["gi"]][0] == g["op"]
+                assert (g["bt"], g["bc"]) == (gates[g["gi"]][1], gates[g["gi"]][2]) and g["slot"] == gates[g["gi"]][3]
+                apply_gate(out, g["op"], g["bt"], g["bc"], theta[g["slot"]], None, n)
+                seen.append(g["gi"])
+
         for rd in st["rounds"]:
             if rd["kind"] == 1:
                 ntab += 1
-                for g in plan["tables"][rd["table"]]:
-                    assert g["op"] in (OP_RZ, OP_CRZ) and gates[g["gi"]][0] == g["op"]
-                    assert (g["bt"], g["bc"]) == (gates[g["gi"]][1], gates[g["gi"]][2]) and g["slot"] == gates[g["gi"]][3]
-                    apply_gate(out, g["op"], g["bt"], g["bc"], theta[g["slot"]], None, n)
-                    seen.append(g["gi"])
+                run_table(rd["table"], rd["tslot"])
                 continue
+            if rd["tab_pre"] >= 0:      # applied to the amplitudes as the round loads them
+                ntab += 1
+                run_table(rd["tab_pre"], rd["ts_pre"])
             rb = rd["rb"]
             assert len(rb) == plan["rbits"] and rb == sorted(rb) and all(0 <= p < st["nloc"] for p in rb)
             for g in rd["gates"]:
@@ -172,7 +182,11 @@ def test_plan_is_equivalent_to_the_program(ansatz, n, layers):
                 apply_gate(out, op, tb, cb, theta[slot] if op != OP_U4 and slot >= 0 else 0.0,
                            U[slot] if op == OP_U4 else None, n)
                 seen.append(g["gi"])
-        assert sorted(pidx_seen) == list(range(st["np"])) and ntab == st["ntab"] <= 2
+            if rd["tab_post"] >= 0:     # applied before the round stores them
+                ntab += 1
+                run_table(rd["tab_post"], rd["ts_post"])
+        assert sorted(pidx_seen) == list(range(st["np"])) and ntab == st["ntab"] <= 1
+        assert sorted(tslots) == list(range(ntab))             # every table owns one t accumulator of the stage
     assert sorted(seen) == list(range(first, len(gates)))     # every gate exactly once
     assert np.abs(out - ref).max() < 1e-10 * np.abs(ref).max()
 
@@ -181,7 +195,7 @@ def test_cross_mesh_16_runs_in_two_stages():
     """BASELINE config 5: 307 gates after folding the leading RX layer -> 2 passes over HBM per direction."""
     circuits = pkg("circuits")
     plan = describe(circuits.build_program("cross_mesh", 16, 1, use_haar=True))
-    assert len(plan["stages"]) == 2 and len(plan["tables"]) == 2
-    assert sum(len(t) for t in plan["tables"]) >= 256 + 12      # the 240 CRZ + 16 RZ of the mesh are one table
+    assert len(plan["stages"]) == 2
+    assert [len(t) for t in plan["tables"]] == [256]            # the 240 CRZ + 16 RZ of the mesh are ONE phase table
     rounds = sum(1 for st in plan["stages"] for r in st["rounds"])
-    assert rounds <= 9, rounds                                  # LDS round trips per statevector: 9, not one per gate (307)
+    assert rounds <= 10, rounds                                 # LDS round trips per statevector: <= 10, not one per gate (307)

@@ -63,8 +63,10 @@ if __name__ == "__main__":
     ap.add_argument("--b5", type=int, default=8192)
     ap.add_argument("--skip3", action="store_true")
     ap.add_argument("--skip5", action="store_true")
+    ap.add_argument("--steps5", type=int, default=2)
+    ap.add_argument("--steps3", type=int, default=5)
     a = ap.parse_args()
     if not a.skip3:
-        run("config 3", 8, "layered", 2, a.b3, steps=5, warmup=2)
+        run("config 3", 8, "layered", 2, a.b3, steps=a.steps3, warmup=2 if a.steps3 > 1 else 1)
     if not a.skip5:
-        run("config 5", 16, "cross_mesh", 1, a.b5, steps=2, warmup=1)
+        run("config 5", 16, "cross_mesh", 1, a.b5, steps=a.steps5, warmup=1)
