@@ -27,6 +27,14 @@
 
 #include <vector>
 
+// Diagnostic, timing-only builds (results are wrong): -DH2_ABLATE_GATES skips the gate arithmetic of the rounds,
+// -DH2_ABLATE_SYNC drops the block barriers of the stage kernel.  Never defined for the shipped library.
+#ifdef H2_ABLATE_SYNC
+#define H2_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define H2_SYNC() __syncthreads()
+#endif
+
 namespace {
 
 struct Cplx {
@@ -138,33 +146,44 @@ __device__ __forceinline__ int h2_uni(int v) { return __builtin_amdgcn_readfirst
 __device__ __forceinline__ float h2_unif(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
+// Read-only plan / coefficient records through the constant address space with a wave-uniform pointer: scalar loads
+// (s_load_dwordxN into SGPRs) instead of per-lane global loads followed by readfirstlane.
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(4))) T* h2_const(const T* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+  return (const __attribute__((address_space(4))) T*)(((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ H2Round h2_load_round(const H2Round* p) {
+  const auto* c = h2_const(p);
   H2Round r;
-  r.kind = h2_uni(p->kind);
-  r.nrb = h2_uni(p->nrb);
+  r.kind = c->kind;
+  r.nrb = c->nrb;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) r.rb[j] = h2_uni(p->rb[j]);
-  r.g0 = h2_uni(p->g0);
-  r.ng = h2_uni(p->ng);
-  r.table = h2_uni(p->table);
-  r.tslot = h2_uni(p->tslot);
-  r.tab_pre = h2_uni(p->tab_pre);
-  r.ts_pre = h2_uni(p->ts_pre);
-  r.tab_post = h2_uni(p->tab_post);
-  r.ts_post = h2_uni(p->ts_post);
+  for (int j = 0; j < 4; ++j) r.rb[j] = c->rb[j];
+  r.g0 = c->g0;
+  r.ng = c->ng;
+  r.table = c->table;
+  r.tslot = c->tslot;
+  r.tab_pre = c->tab_pre;
+  r.ts_pre = c->ts_pre;
+  r.tab_post = c->tab_post;
+  r.ts_post = c->ts_post;
   return r;
 }
 __device__ __forceinline__ H2Gate h2_load_gate(const H2Gate* p) {
+  const auto* c = h2_const(p);
   H2Gate g;
-  g.op = h2_uni(p->op);
-  g.kind = h2_uni(p->kind);
-  g.tq = h2_uni(p->tq);
-  g.cq = h2_uni(p->cq);
-  g.tbit = h2_uni(p->tbit);
-  g.cbit = h2_uni(p->cbit);
-  g.gi = h2_uni(p->gi);
-  g.slot = h2_uni(p->slot);
-  g.pidx = h2_uni(p->pidx);
+  g.op = c->op;
+  g.kind = c->kind;
+  g.tq = c->tq;
+  g.cq = c->cq;
+  g.tbit = c->tbit;
+  g.cbit = c->cbit;
+  g.gi = c->gi;
+  g.slot = c->slot;
+  g.pidx = c->pidx;
   return g;
 }
 
@@ -305,16 +324,16 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
   // registers that live across the channel loop
   Cplx x0[!BWD && LASTC ? R : 1];     // forward, last stage: final value-channel tile
   Cplx l0acc[BWD && LASTC ? R : 1];   // backward, last stage: lam_0 = sum_c D_c chi_c
-  float tacc0[BWD && TABC ? R : 1];   // backward: t = sum_c Im(conj lam chi) at the stage's table
+  float tacc0[BWD && TABC ? R : 1], tacc1[BWD && TABC ? R : 1];   // backward: t = sum_c Im(conj lam chi) per table
   if constexpr (BWD && LASTC) {
 #pragma unroll
     for (int q = 0; q < R; ++q) l0acc[q] = {0.f, 0.f};
   }
   if constexpr (BWD && TABC) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) tacc0[q] = 0.f;
+    for (int q = 0; q < R; ++q) tacc0[q] = tacc1[q] = 0.f;
   }
-  __syncthreads();
+  H2_SYNC();
 
   if constexpr (BWD && LASTC) {
     if (A.last) {
@@ -337,7 +356,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
         }
         s_Dg[tid] = s;
       }
-      __syncthreads();
+      H2_SYNC();
     }
   }
   auto Dval = [&](int c, int l) { return s_Dg[c] + s_D[c][l & 63] + s_D[c][64 + (l >> 6)]; };
@@ -457,14 +476,14 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
         const float wv = qc_wave_sum_to_lane63(mine);
         if (lane == 63) s_red[wave][b] = wv;
       }
-      __syncthreads();
+      H2_SYNC();
       if (tid < n) {
         float s = 0.f;
         for (int w = 0; w < NW; ++w) s += s_red[w][tid];
         const int ch8 = pass ? 6 + (c - 2) : c;
         A.xpart[(((size_t)ch8 * A.pt_stride + pt) * ntau + tau) * H2_XW + tid] = s;
       }
-      __syncthreads();
+      H2_SYNC();
     }
   };
   // per-thread part of a round mapping: positions outside the register set rb[] take the bits of the thread index
@@ -494,7 +513,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
     const int c = BWD ? (ci + 1 < NCH ? ci + 1 : 0) : ci;
     if (gen) {
       gen_tables(c);
-      __syncthreads();
+      H2_SYNC();
     }
     // ---------------- load phase through LDS (linear mapping) unless the first round reads HBM itself
     if (!din) {
@@ -522,7 +541,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           t1[tsw ^ lin_sw[q]] = y;
         }
       }
-      __syncthreads();
+      H2_SYNC();
     }
 
     // ---------------- rounds
@@ -542,12 +561,15 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           } else {
             const Cplx x = t0[li], y = t1[li];
             const float tv = y.re * x.im - y.im * x.re;   // Im(conj(lam) chi), invariant under the run's gates
-            if constexpr (TABC) tacc0[q] += tv;
+            if constexpr (TABC) {
+              if (rd.tslot == 0) tacc0[q] += tv;
+              else tacc1[q] += tv;
+            }
             t0[li] = cmulc(x, ph);
             t1[li] = cmulc(y, ph);
           }
         }
-        __syncthreads();
+        H2_SYNC();
         continue;
       }
       // gate round: per-thread and per-q parts of the mapping
@@ -623,7 +645,10 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             v[0].im[q] = x.im;
           } else {
             const float tv = v[1].re[q] * v[0].im[q] - v[1].im[q] * v[0].re[q];
-            if constexpr (TABC) tacc0[q] += tv;
+            if constexpr (TABC) {
+              if (tslot == 0) tacc0[q] += tv;
+              else tacc1[q] += tv;
+            }
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
               const Cplx x = cmulc({v[k].re[q], v[k].im[q]}, ph);
@@ -635,12 +660,17 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
       };
       if (!BWD && rd.tab_pre >= 0) table_here(rd.tab_pre, rd.ts_pre);
       if (BWD && rd.tab_post >= 0) table_here(rd.tab_post, rd.ts_post);
+#ifdef H2_ABLATE_GATES
+      for (int gi = 0; gi < 0; ++gi) {
+#else
       for (int gi = 0; gi < rd.ng; ++gi) {
+#endif
         const H2Gate hg = h2_load_gate(A.gates + rd.g0 + (BWD ? rd.ng - 1 - gi : gi));
         float c_ = 1.f, s_ = 0.f;
         if (hg.op != QC_U4 && hg.slot >= 0) {
-          c_ = h2_unif(A.trig[hg.gi].c);
-          s_ = h2_unif(A.trig[hg.gi].s);
+          const auto* tr = h2_const(A.trig + hg.gi);
+          c_ = tr->c;
+          s_ = tr->s;
         }
         float grad = 0.f;
         switch (hg.kind) {
@@ -699,9 +729,9 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           }
           case H2_K_U4: {
             float us[32];   // the 4x4 matrix in SGPRs
-            const float* um = A.umat + (hg.slot * 2 + (BWD ? 1 : 0)) * 32;
+            const auto* um = h2_const(A.umat + (hg.slot * 2 + (BWD ? 1 : 0)) * 32);
 #pragma unroll
-            for (int i = 0; i < 32; ++i) us[i] = h2_unif(um[i]);
+            for (int i = 0; i < 32; ++i) us[i] = um[i];
             h2_apply_u4<RB, KV>(v, hg.tq, hg.cq, us);
             break;
           }
@@ -750,7 +780,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           t0[li] = {v[0].re[q], v[0].im[q]};
           if constexpr (BWD) t1[li] = {v[1].re[q], v[1].im[q]};
         }
-        __syncthreads();
+        H2_SYNC();
       }
     }
 
@@ -813,19 +843,19 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             }
 #pragma unroll
             for (int q = 0; q < R; ++q) t1[sl2 ^ h2_swz<RB>(q << (grp * RB))] = {u[0].re[q], u[0].im[q]};
-            __syncthreads();
+            H2_SYNC();
           }
           Cplx* xo = A.xi + (((size_t)c * A.pt_stride + pt) * ntau + tau) * A.nx;
           for (int j = tid; j < A.nx; j += NT) xo[j] = t1[h2_swz<RB>(A.sparse_idx[j])];
         }
       }
     }
-    if (uses_lds || gen) __syncthreads();   // the next channel overwrites the tile / the series tables
+    if (uses_lds || gen) H2_SYNC();   // the next channel overwrites the tile / the series tables
   }
 
   if constexpr (BWD) {
     // in-round gate gradients of this block
-    __syncthreads();
+    H2_SYNC();
     for (int i = tid; i < sd.np; i += NT) {
       float s = 0.f;
       for (int w = 0; w < NW; ++w) s += s_g[w][i];
@@ -833,15 +863,15 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
     }
     // diagonal tables: Walsh-Hadamard transform of t over the local bits, coefficients of weight <= 2
     float* tf = reinterpret_cast<float*>(smem_raw);
-    for (int k = 0; k < (TABC ? sd.ntab : 0); ++k) {   // (H2_MAXTAB = 1: one accumulator)
-      __syncthreads();
+    for (int k = 0; k < (TABC ? sd.ntab : 0); ++k) {
+      H2_SYNC();
       {
         // t was accumulated in the mapping of the round the table rides on
         const H2Round rt = h2_load_round(A.rounds + sd.r0 + sd.tab_round[k]);
         if (rt.kind == H2_ROUND_TABLE) {
           const int tsw = h2_swz<RB>(ftid());
 #pragma unroll
-          for (int q = 0; q < R; ++q) tf[tsw ^ lin_sw[q]] = tacc0[TABC ? q : 0];
+          for (int q = 0; q < R; ++q) tf[tsw ^ lin_sw[q]] = k == 0 ? tacc0[TABC ? q : 0] : tacc1[TABC ? q : 0];
         } else {
           const int sl = h2_swz<RB>(round_lbase(rt.rb));
 #pragma unroll
@@ -849,11 +879,11 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             int o = 0;
 #pragma unroll
             for (int j = 0; j < RB; ++j) o |= ((q >> j) & 1) << rt.rb[j];
-            tf[sl ^ h2_swz<RB>(o)] = tacc0[TABC ? q : 0];
+            tf[sl ^ h2_swz<RB>(o)] = k == 0 ? tacc0[TABC ? q : 0] : tacc1[TABC ? q : 0];
           }
         }
       }
-      __syncthreads();
+      H2_SYNC();
       for (int grp = 0; grp < nloc / RB; ++grp) {
         int rbg[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -874,7 +904,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
         }
 #pragma unroll
         for (int q = 0; q < R; ++q) tf[sl2 ^ h2_swz<RB>(q << (grp * RB))] = u[q];
-        __syncthreads();
+        H2_SYNC();
       }
       for (int j = tid; j < A.nc; j += NT) A.dpart[((size_t)k * nblk + blk) * A.nc + j] = tf[h2_swz<RB>(A.wht_idx[j])];
     }

@@ -26,8 +26,8 @@
 constexpr int H2_T = 12;        // local bits per tile (32 KiB of complex64)
 constexpr int H2_LOW = 4;       // low bits that are always local
 constexpr int H2_MAXP = 64;     // parametric in-round gates per stage (LDS accumulator rows)
-constexpr int H2_MAXTAB = 1;    // diagonal tables per stage (one register accumulator of t per thread)
-constexpr int H2_TABLE_MIN = 24; // shortest diagonal run that becomes a table (shorter runs ride in rounds as phase gates)
+constexpr int H2_MAXTAB = 2;    // diagonal tables per stage (register accumulators of t)
+constexpr int H2_TABLE_MIN = 8; // shortest diagonal run that becomes a table (shorter runs ride in rounds as phase gates)
 constexpr int H2_MAXRG = 24;    // gates per round (parametric ones need a partial-sum register each: <= 8 of them)
 constexpr int H2_MAXRP = 8;
 

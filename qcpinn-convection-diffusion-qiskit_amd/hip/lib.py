@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libqcpinn_hip.so")
+# (QC_LIB: a diagnostic build of the same library, e.g. the timing-only ablation variants of tools/ablate_hbm.sh)
+LIB_PATH = os.environ.get("QC_LIB") or os.path.join(os.path.dirname(_HERE), "libqcpinn_hip.so")
 
 QC_PHASE_GRADS = 1
 QC_PHASE_UPDATE = 2
