@@ -1145,13 +1145,17 @@ static int h2_max_ntau(const H2Plan& P) {
   return m;
 }
 
+// 12-bit tiles: 8 amplitudes per thread x 512 threads by default (four waves per SIMD without spills in the
+// backward kernels); QC_H2_RB=4 selects 16 amplitudes x 256 threads (fewer rounds, two waves per SIMD)
+static int h2_rb12() {
+  static const int rb12 = [] { const char* e = getenv("QC_H2_RB"); return (e && e[0] == '4') ? 4 : 3; }();
+  return rb12;
+}
+
 void* qc_h2_create(const qc_program* pg, int absorb) {
   QcH2* h = new QcH2();
   H2Dev& D = h->dev;
-  // 12-bit tiles: 8 amplitudes per thread x 512 threads by default (four waves per SIMD without spills in the
-  // backward kernels); QC_H2_RB=4 selects 16 amplitudes x 256 threads (fewer rounds, two waves per SIMD)
-  static const int rb12 = [] { const char* e = getenv("QC_H2_RB"); return (e && e[0] == '4') ? 4 : 3; }();
-  D.plan = h2_make_plan(pg->h_gates, pg->n_gates, pg->n_qubits, absorb, rb12);
+  D.plan = h2_make_plan(pg->h_gates, pg->n_gates, pg->n_qubits, absorb, h2_rb12());
   const H2Plan& P = D.plan;
   const int nl0 = P.stages[0].nloc;
   std::vector<int> rank((size_t)1 << nl0, -1);
@@ -1209,7 +1213,7 @@ void qc_h2_destroy(void* hp) {
 }
 
 int qc_h2_describe_gates(const QcGate* gates, int n_gates, int n_qubits, int absorb, int32_t* out, int cap) {
-  const std::vector<int> d = h2_describe(h2_make_plan(gates, n_gates, n_qubits, absorb));
+  const std::vector<int> d = h2_describe(h2_make_plan(gates, n_gates, n_qubits, absorb, h2_rb12()));
   if (out)
     for (int i = 0; i < cap && i < (int)d.size(); ++i) out[i] = d[i];
   return (int)d.size();

@@ -721,20 +721,29 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
   for (int i = threadIdx.x; i < 3 * n_params; i += 192) s_acc[i] = 0.f;
   // wires wv, wv + 3, ... of the embedding half-angles
   for (int w = wv; w < N; w += 3) qc_wire_sincos(s_cs[w * 64 + lane], s_cs[(N + w) * 64 + lane], ajets, B, pc, w, trig, amp >> 1);
+  // the point index as an opaque value: addresses derived from it are recomputed at their use instead of being hoisted
+  // above the two-channel loop and held (or spilled) for the whole kernel
+  auto pcf = [&]() {
+    int64_t v = pc;
+    asm volatile("" : "+v"(v));
+    return v;
+  };
   const int cha = wv == 0 ? 1 : wv + 1;        // first channel of this wave: t, x, y
   const int chb = wv == 0 ? 0 : wv + 3;        // second: value, xx, yy
 
   auto load_chi = [&](SV<N>& v, int c) {
+    const int64_t pq = pcf();
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
-      v.re[k] = chi_store[qc_chi_index<A2>(c, 2 * k, pc)];
-      v.im[k] = chi_store[qc_chi_index<A2>(c, 2 * k + 1, pc)];
+      v.re[k] = chi_store[qc_chi_index<A2>(c, 2 * k, pq)];
+      v.im[k] = chi_store[qc_chi_index<A2>(c, 2 * k + 1, pq)];
     }
   };
   auto dvec = [&](int c, float (&d)[NA]) {
     float qb[N];
+    const int64_t pq = pcf();
 #pragma unroll
-    for (int w = 0; w < N; ++w) qb[w] = live ? qbar[((int64_t)c * N + w) * B + pc] : 0.f;
+    for (int w = 0; w < N; ++w) qb[w] = live ? qbar[((int64_t)c * N + w) * B + pq] : 0.f;
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
       float s = 0.f;
@@ -764,15 +773,16 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
         cl[1].im[k] *= da_[k];
       }
     } else {                  // lam_x = D_x chi_0 + 2 D_xx chi_x (the same for y)
+      const int64_t pq = pcf();
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
-        const float br = chi_store[qc_chi_index<A2>(chb, 2 * k, pc)], bi = chi_store[qc_chi_index<A2>(chb, 2 * k + 1, pc)];
+        const float br = chi_store[qc_chi_index<A2>(chb, 2 * k, pq)], bi = chi_store[qc_chi_index<A2>(chb, 2 * k + 1, pq)];
         mine[(2 * k) * 64 + lane] = fmaf(da_[k], cl[0].re[k], d[k] * br);
         mine[(2 * k + 1) * 64 + lane] = fmaf(da_[k], cl[0].im[k], d[k] * bi);
       }
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
-        const float x0r = chi_store[qc_chi_index<A2>(0, 2 * k, pc)], x0i = chi_store[qc_chi_index<A2>(0, 2 * k + 1, pc)];
+        const float x0r = chi_store[qc_chi_index<A2>(0, 2 * k, pq)], x0i = chi_store[qc_chi_index<A2>(0, 2 * k + 1, pq)];
         cl[1].re[k] = fmaf(2.f * d[k], cl[0].re[k], da_[k] * x0r);
         cl[1].im[k] = fmaf(2.f * d[k], cl[0].im[k], da_[k] * x0i);
       }
@@ -799,10 +809,11 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
         }
       } else {                // lam_xx = D_xx chi_0
         dvec(chb, d);
+        const int64_t pq = pcf();
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-          cl[1].re[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k, pc)];
-          cl[1].im[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k + 1, pc)];
+          cl[1].re[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k, pq)];
+          cl[1].im[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k + 1, pq)];
         }
       }
     }
@@ -810,13 +821,14 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
 
     // cotangents of the angle jets in the frame pulled back through the embedding (qc_gates.h)
     float ca[N], sa[N], da[N], dda[N];
-    load_sincos<N>(ca, sa, aj, B, pc, trig, amp >> 1, s_cs);
+    const int64_t pq = pcf();
+    load_sincos<N>(ca, sa, aj, B, pq, trig, amp >> 1, s_cs);
     qc_unembed<N>(cl[1], ca, sa);
     const int dirch = ch == 0 ? 0 : (ch <= 3 ? ch : ch - 2);
 #pragma unroll
     for (int w = 0; w < N; ++w) {
-      da[w] = ch >= 1 ? aj[((int64_t)dirch * N + w) * B + pc] : 0.f;
-      dda[w] = ch >= 4 ? aj[((int64_t)ch * N + w) * B + pc] : 0.f;
+      da[w] = ch >= 1 ? aj[((int64_t)dirch * N + w) * B + pq] : 0.f;
+      dda[w] = ch >= 4 ? aj[((int64_t)ch * N + w) * B + pq] : 0.f;
     }
     float T[N];
     if (ch == 0) {
