@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 2
+#define QC_ABI_VERSION 3
 
 typedef struct qc_program qc_program; /* device-resident gate program (opaque) */
 
@@ -194,6 +194,9 @@ typedef struct qc_step_desc {
   uint64_t sample_seed, sample_step;
   int64_t sample_bc_face_points; /* 0: BC batch on the x=0 face; > 0: four faces, see qc_sample_collocation_faces */
   void* circ_ws_dev; size_t circ_ws_bytes;   /* qc_step_workspace_bytes(prog, B_res, B_val); NULL/0 allowed for angle encoding at n <= 8 */
+  /* data parallelism inside the library: a communicator of qc_comm_create (or NULL).  With it a call with
+   * QC_PHASE_GRADS | QC_PHASE_UPDATE all-reduces flat_dev across the ranks between the two phases, on `stream`. */
+  void* comm;
 } qc_step_desc;
 
 /* Scratch for one fused step on B_res residual points: the HBM statevector tile for n >= 9; for the
@@ -212,6 +215,16 @@ size_t qc_step_workspace_bytes(const qc_program* prog, int64_t B_res, int64_t B_
 #define QC_STAGE_PRE_BWD 4
 #define QC_STAGE_COUNT 5
 int qc_fused_step_stage(const qc_step_desc* desc, int stage, void* stream);
+
+/* ---- data-parallel collective (collocation batches shard over the GPUs of a node, ONE all-reduce of the
+ * flat [gradient | L_r, L_bc, L_ic] vector per step; the reference is single-process and has no counterpart).  RCCL over
+ * xGMI, loaded on first use (QC_ERR_UNSUPPORTED when librccl is not available).  Call with the rank's device current.
+ * id: 128 bytes (ncclUniqueId), produced on one rank and distributed to the others by the caller's own means. */
+int qc_comm_unique_id(void* id_out_128_bytes);
+int qc_comm_create(const void* id_128_bytes, int world_size, int rank, void** comm_out);
+int qc_comm_destroy(void* comm);
+/* in-place sum over the ranks of `count` floats (fp32) on `stream` */
+int qc_allreduce_grads(float* buf_dev, int64_t count, void* comm, void* stream);
 
 #define QC_PHASE_GRADS 1
 #define QC_PHASE_UPDATE 2

@@ -681,7 +681,7 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
     // the step owns its partial-row matrix, so the reduction folds it in place (two levels, fixed order);
     // with the update phase in the same call the second level rides in the optimiser launch
     const int RS = qc_opt_fold_rows(d->part_dev, rows, d->part_stride, L.NP + 3, st);
-    if (phases & QC_PHASE_UPDATE) {
+    if ((phases & QC_PHASE_UPDATE) && !d->comm) {
       if (!d->m_dev || !d->v_dev || !d->opt_state_dev) return QC_ERR_ARG;
       QcOptHyper h;
       memcpy(&h, &d->hyper, sizeof(h));
@@ -690,6 +690,8 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       return after_launch();
     }
     if ((rc = qc_reduce_rows(d->part_dev, RS, d->part_stride, L.NP + 3, d->flat_dev, st))) return rc;
+    // data parallelism inside the library: sum the flat [gradient | 3 loss sums] vector over the ranks (RCCL, same stream)
+    if (d->comm && (phases & QC_PHASE_UPDATE) && (rc = qc_comm_allreduce(d->flat_dev, L.NP + 3, d->comm, st))) return rc;
   }
   if (phases & QC_PHASE_UPDATE) {
     if (!d->m_dev || !d->v_dev || !d->opt_state_dev) return QC_ERR_ARG;

@@ -136,5 +136,6 @@ int qc_h2_forward(const qc_program* pg, void* h2, const QcTrig* trig, const floa
 int qc_h2_backward(const qc_program* pg, void* h2, const QcTrig* trig, const float* umat, const float* ajets, const float* qbar,
                    float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, void* ws, size_t ws_bytes,
                    bool resident, hipStream_t st);
+int qc_comm_allreduce(float* buf, int64_t count, void* comm, hipStream_t st);   // qc_comm.hip: RCCL sum, fp32, in place
 int qc_amp_fwd_launch(const float* a, float* u, int n, int64_t B, int nch, hipStream_t);
 int qc_amp_bwd_launch(const float* a, const float* ub, float* ab, int n, int64_t B, int nch, hipStream_t);

@@ -200,6 +200,7 @@ class SolverEngine:
         self.flat = _need(flat_params, self.device, "flat params")
         self.D, self.vx, self.vy = float(D), float(vx), float(vy)
         self.sigma = (1.0, 1.0, 1.0)                           # sigma_t, sigma_x, sigma_y of nn/pde.py:53-70
+        self.coeffs = None      # explicit (c_t, c_x, c_y, d_xx, d_yy) of another linear operator on the same channels
         self.problem = L.QC_PROBLEM_CONVECTION_DIFFUSION      # analytic targets of the fused loss (qcpinn_hip.h)
         self._fused: Dict[Tuple[int, int, int], "FusedStep"] = {}
 
@@ -208,8 +209,9 @@ class SolverEngine:
         # loss = 2*MSE_res + 4*MSE_bc + 2*MSE_ic (trainer/diffusion_train.py:47); d/d(err) = 2*w/N * err
         # u_k/sigma_k and u_kk/sigma_k^2 (nn/pde.py:60-70) are scalings of channels the kernels already carry
         st, sx, sy = self.sigma
-        return L.QcPde(self.D, self.vx, self.vy, 1.0 / st, self.vx / sx, self.vy / sy, self.D / (sx * sx),
-                       self.D / (sy * sy), 4.0 / n_res, 1.0 / n_res, 4.0 / n_ic, 8.0 / n_bc,
+        co = self.coeffs if self.coeffs is not None else (1.0 / st, self.vx / sx, self.vy / sy, self.D / (sx * sx),
+                                                          self.D / (sy * sy))
+        return L.QcPde(self.D, self.vx, self.vy, co[0], co[1], co[2], co[3], co[4], 4.0 / n_res, 1.0 / n_res, 4.0 / n_ic, 8.0 / n_bc,
                        1.0 / n_ic, 1.0 / n_bc, self.problem, n_seg_a)
 
     def refresh_gates(self) -> None:
@@ -284,7 +286,7 @@ class SolverEngine:
 
     # ------------------------------------------------------------------ fused training step
     def fused(self, B_res: int, n_ic: int, n_bc: int, opt: "OptimState", counts=None) -> "FusedStep":
-        key = (B_res, n_ic, n_bc, id(opt), counts, self.problem, self.D, self.vx, self.vy, self.sigma)
+        key = (B_res, n_ic, n_bc, id(opt), counts, self.problem, self.D, self.vx, self.vy, self.sigma, self.coeffs)
         if key not in self._fused:
             self._fused[key] = FusedStep(self, B_res, n_ic, n_bc, opt, counts)
         return self._fused[key]
@@ -378,6 +380,7 @@ class FusedStep:
         self.step_ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
         d.circ_ws_dev, d.circ_ws_bytes = (self.step_ws.data_ptr(), need) if need else (None, 0)
         d.n_ic = n_ic
+        d.comm = None
         d.sample_off_res = d.sample_off_ic = d.sample_off_bc = 0
         d.sample_seed, d.sample_step = 0, 0
         d.sample_bc_face_points = 0
@@ -392,6 +395,11 @@ class FusedStep:
         d.sample_bc_face_points = bc_face_points
         d.sample_seed = seed & 0xFFFFFFFFFFFFFFFF
         d.sample_off_res, d.sample_off_ic, d.sample_off_bc = off_res, off_ic, off_bc
+
+    def set_comm(self, comm) -> None:
+        """A communicator of ``qc_comm_create`` (or None): GRADS | UPDATE in one call then all-reduces the flat
+        [gradient | 3 loss sums] vector across the ranks inside the library (RCCL, same stream)."""
+        self.desc.comm = comm
 
     def run(self, phases: int = L.QC_PHASE_GRADS | L.QC_PHASE_UPDATE) -> None:
         if phases & L.QC_PHASE_SAMPLE:

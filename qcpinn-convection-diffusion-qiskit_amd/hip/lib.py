@@ -26,7 +26,7 @@ EXPORTS = (
     "qc_circuit_workspace_bytes", "qc_circuit_workspace_bytes_batch", "qc_hbm_plan_describe", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_forward_jets_keep", "qc_backward_jets_kept", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
     "qc_sample_collocation", "qc_sample_collocation_faces", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
-    "qc_fused_step_stage",
+    "qc_fused_step_stage", "qc_comm_unique_id", "qc_comm_create", "qc_comm_destroy", "qc_allreduce_grads",
 )
 
 
@@ -71,6 +71,7 @@ class QcStepDesc(C.Structure):
         ("sample_off_bc", C.c_int64), ("sample_seed", C.c_uint64), ("sample_step", C.c_uint64),
         ("sample_bc_face_points", C.c_int64),
         ("circ_ws_dev", C.c_void_p), ("circ_ws_bytes", C.c_size_t),
+        ("comm", C.c_void_p),
     ]
 
 
@@ -123,6 +124,10 @@ def load() -> C.CDLL:
     lib.qc_amp_forward.argtypes = [fp, fp, i32, i64, i32, vp]
     lib.qc_amp_backward.argtypes = [fp, fp, fp, i32, i64, i32, vp]
     lib.qc_fused_pinn_residual_step.argtypes = [C.POINTER(QcStepDesc), i32, vp]
+    lib.qc_comm_unique_id.argtypes = [vp]
+    lib.qc_comm_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    lib.qc_comm_destroy.argtypes = [vp]
+    lib.qc_allreduce_grads.argtypes = [fp, i64, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("qc_error_string", "qc_trig_bytes", "qc_circuit_workspace_bytes", "qc_circuit_workspace_bytes_batch",

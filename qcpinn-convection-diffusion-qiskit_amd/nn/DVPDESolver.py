@@ -30,7 +30,7 @@ class _ValueFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, solver, *params):
         eng = solver._engine_for(X.device)
-        Xc = X.detach().to(torch.float32).contiguous()
+        Xc = solver._pad_inputs(X.detach().to(torch.float32)).contiguous()
         u, _, ajets, qjets = eng.forward(Xc, 1)
         ctx.eng, ctx.solver = eng, solver
         ctx.save_for_backward(Xc, ajets, qjets)
@@ -51,8 +51,8 @@ class _ResidualFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, X, solver, pde, *params):
         eng = solver._engine_for(X.device)
-        eng.D, eng.vx, eng.vy, eng.sigma = pde
-        Xc = X.detach().to(torch.float32).contiguous()
+        eng.D, eng.vx, eng.vy, eng.sigma, eng.coeffs = pde
+        Xc = solver._pad_inputs(X.detach().to(torch.float32)).contiguous()
         u, res, ajets, qjets = eng.forward(Xc, _engine.NCH)
         ctx.eng, ctx.solver, ctx.pde = eng, solver, pde
         ctx.save_for_backward(Xc, ajets, qjets)
@@ -63,7 +63,7 @@ class _ResidualFn(torch.autograd.Function):
     def backward(ctx, gu, gres):
         Xc, ajets, qjets = ctx.saved_tensors
         eng = ctx.eng
-        eng.D, eng.vx, eng.vy, eng.sigma = ctx.pde
+        eng.D, eng.vx, eng.vy, eng.sigma, eng.coeffs = ctx.pde
         eng.refresh_gates()
         d_flat = eng.backward(Xc, ajets, qjets, gu, gres, _engine.NCH)
         return (None, None, None) + ctx.solver._split_flat(d_flat)
@@ -87,9 +87,10 @@ class DVPDESolver(nn.Module):
         self.classic_network = self.args["classic_network"]
         self.total_training_time = 0
         self.total_memory_peak = 0
-        if self.classic_network[0] != 3 or self.classic_network[-1] != 1:
-            raise ValueError("the convection-diffusion DV path maps (t, x, y) -> u: classic_network must be "
-                             f"[3, H, 1], got {self.classic_network}")
+        if self.classic_network[0] not in (2, 3) or self.classic_network[-1] != 1:
+            raise ValueError("the DV path maps (t, x, y) -> u (or two coordinates -> u for the second-order operators of "
+                             f"nn/pde.py): classic_network must be [3, H, 1] or [2, H, 1], got {self.classic_network}")
+        self.input_dim = self.classic_network[0]
         hidden = self.classic_network[-2]
 
         # same construction order as the reference => same RNG consumption (nn/DVPDESolver.py:28-57)
@@ -136,15 +137,30 @@ class DVPDESolver(nn.Module):
     def hidden_width(self) -> int:
         return self.classic_network[-2]
 
+    def _slots(self):
+        """(parameter, flat slots it occupies) in ``model.parameters()`` order.  A two-input model keeps its first
+        layer as W1[H][3] in the flat buffer with a zero column in front (the kernels' coordinate slots are (t, x, y);
+        the two inputs ride in the x and y slots, the ones with second derivatives)."""
+        out = []
+        for p in _flat_param_list(self):
+            pad = self.input_dim == 2 and p is self.preprocessor[0].weight
+            out.append((p, p.shape[0] * 3 if pad else p.numel(), pad))
+        return out
+
     def _pack(self, device) -> None:
         """Move every parameter into one flat buffer on ``device`` and re-point the Parameters at
         views of it (``model.parameters()`` order = kernel layout, see hip/engine.param_layout)."""
-        plist = _flat_param_list(self)
-        flat = torch.cat([p.detach().reshape(-1).to(device=device, dtype=torch.float32) for p in plist])
+        slots = self._slots()
+        parts = []
+        for p, k, pad in slots:
+            v = p.detach().to(device=device, dtype=torch.float32)
+            if pad:
+                v = torch.cat([torch.zeros(v.shape[0], 1, device=device), v], dim=1)
+            parts.append(v.reshape(-1))
+        flat = torch.cat(parts)
         off = 0
-        for p in plist:
-            k = p.numel()
-            p.data = flat[off:off + k].view(p.shape)
+        for p, k, pad in slots:
+            p.data = flat[off:off + k].view(p.shape[0], 3)[:, 1:3] if pad else flat[off:off + k].view(p.shape)
             off += k
         self._flat = flat
         self._engines = {}
@@ -154,11 +170,19 @@ class DVPDESolver(nn.Module):
         if self._flat is None:
             return False
         off = 0
-        for p in _flat_param_list(self):
-            if p.device != self._flat.device or p.data_ptr() != self._flat.data_ptr() + 4 * off:
+        for p, k, pad in self._slots():
+            if p.device != self._flat.device or p.data_ptr() != self._flat.data_ptr() + 4 * (off + (1 if pad else 0)):
                 return False
-            off += p.numel()
+            off += k
         return off == self._flat.numel()
+
+    def _pad_inputs(self, X):
+        """(B, 2) inputs of a two-input model -> the kernels' (t, x, y) slots: (0, X[:, 0], X[:, 1])."""
+        if self.input_dim == 2:
+            if X.shape[1] != 2:
+                raise ValueError(f"this model takes (B, 2) inputs, got {tuple(X.shape)}")
+            return torch.cat([torch.zeros_like(X[:, :1]), X], dim=1)
+        return X
 
     def _engine_for(self, device) -> "_engine.SolverEngine":
         device = torch.device(device)
@@ -176,9 +200,8 @@ class DVPDESolver(nn.Module):
 
     def _split_flat(self, d_flat):
         out, off = [], 0
-        for p in _flat_param_list(self):
-            k = p.numel()
-            out.append(d_flat[off:off + k].view(p.shape))
+        for p, k, pad in self._slots():
+            out.append(d_flat[off:off + k].view(p.shape[0], 3)[:, 1:3] if pad else d_flat[off:off + k].view(p.shape))
             off += k
         return tuple(out)
 
@@ -191,6 +214,8 @@ class DVPDESolver(nn.Module):
                 self.draw_quantum_circuit(x)
                 self.draw_quantum_circuit_flag = False
             self._engine_for(x.device)
+            if x.shape[1] != self.input_dim:
+                raise ValueError(f"Expected input of shape (B, {self.input_dim}), got {tuple(x.shape)}")
             return _ValueFn.apply(x, self, *_flat_param_list(self))
         except Exception as e:
             if self.logger is not None:
@@ -200,10 +225,21 @@ class DVPDESolver(nn.Module):
     def residual(self, X: torch.Tensor, D=0.01, v_x=1.0, v_y=1.0, sigma=(1.0, 1.0, 1.0)):
         """(u, residual) at X (B,3) with the derivative channels carried through the HIP kernels —
         what ``nn.pde.diffusion_operator`` dispatches to for this model."""
-        if X.dim() != 2 or X.shape[1] != 3:
+        if X.dim() != 2 or X.shape[1] != 3 or self.input_dim != 3:
             raise ValueError(f"Expected collocation points of shape (B, 3), got {tuple(X.shape)}")
         self._engine_for(X.device)
-        pde = (float(D), float(v_x), float(v_y), tuple(float(s) for s in sigma))
+        pde = (float(D), float(v_x), float(v_y), tuple(float(s) for s in sigma), None)
+        return _ResidualFn.apply(X, self, pde, *_flat_param_list(self))
+
+    def second_order(self, X: torch.Tensor, c_aa: float, c_bb: float):
+        """(u, c_aa * u_aa + c_bb * u_bb) for a TWO-input model u(a, b) (X = (B, 2)): the second-derivative channels of
+        the same fused kernels, with the two inputs in the coordinate slots that carry them.  What the Klein-Gordon,
+        wave and Helmholtz operators of ``nn.pde`` dispatch to (reference nn/pde.py:28-52,73-95)."""
+        if X.dim() != 2 or X.shape[1] != 2 or self.input_dim != 2:
+            raise ValueError(f"second_order needs a two-input model and points of shape (B, 2), got {tuple(X.shape)}")
+        self._engine_for(X.device)
+        # residual = c_t u_t + c_x u_x + c_y u_y - (d_xx u_xx + d_yy u_yy)  with (a, b) in the (x, y) slots
+        pde = (0.0, 0.0, 0.0, (1.0, 1.0, 1.0), (0.0, 0.0, 0.0, -float(c_aa), -float(c_bb)))
         return _ResidualFn.apply(X, self, pde, *_flat_param_list(self))
 
     # ------------------------------------------------------------------ checkpoint (same keys as :116-128)

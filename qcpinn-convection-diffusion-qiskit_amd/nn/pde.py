@@ -14,7 +14,10 @@ The other operators of the reference file (nn/pde.py:2-52,73-95: Navier-Stokes 2
 wave, Helmholtz) are provided in the same autograd formulation, with the reference's signatures,
 constants and return shapes.  None of the DV trainers uses them; they run on any model, including
 user-composed models around ``DVQuantumLayer`` (whose ``create_graph=True`` reverse pass supplies the
-second derivatives).  Fused derivative-channel kernels for them are not built.
+second derivatives).  For a two-input ``DVPDESolver`` (``classic_network = [2, H, 1]``) the three scalar
+second-order operators (Klein-Gordon, wave, Helmholtz) take their second derivatives from the fused
+derivative-channel kernels (``DVPDESolver.second_order``: any qubit count, both encodings); the three-output
+Navier-Stokes operator stays on the autograd formulation.
 """
 import torch
 
@@ -67,10 +70,19 @@ def navier_stokes_2D_operator(model, t, x, y, min_x=0, max_x=1):
     return [u_x + v_y, f_u, f_v]
 
 
+def _fused_second_order(model):
+    """A two-input DVPDESolver: second derivatives come from the fused derivative-channel kernels."""
+    return getattr(model, "second_order", None) if getattr(model, "input_dim", 0) == 2 else None
+
+
 def klein_gordon_operator(fluid_model, t, x, x_min=0.0, x_max=1.0):
     """Reference nn/pde.py:28-41: u_tt - u_xx + 0*u + u^3; returns (u, residual)."""
     alpha, beta, gamma, power = -1.0, 0.0, 1.0, 3
     _track(t, x)
+    fused = _fused_second_order(fluid_model)
+    if fused is not None:
+        u, lin = fused(torch.cat((t, x), 1), 1.0, alpha)          # u_tt + alpha u_xx in the kernels
+        return u, lin + beta * u + gamma * u ** power
     u = fluid_model(torch.cat((t, x), 1))
     _, u_tt = _second(u, t)
     _, u_xx = _second(u, x)
@@ -82,6 +94,9 @@ def wave_operator(model, t, x, sigma_t=1.0, sigma_x=1.0):
     the reference, unused); returns (u, residual)."""
     speed = 2
     _track(t, x)
+    fused = _fused_second_order(model)
+    if fused is not None:
+        return fused(torch.cat((t, x), 1), 1.0, -float(speed ** 2))
     u = model(torch.cat((t, x), 1))
     _, u_tt = _second(u, t)
     _, u_xx = _second(u, x)
@@ -92,6 +107,10 @@ def helmholtz_operator(fluid_model, x1, x2):
     """Reference nn/pde.py:73-95: u_x1x1 + u_x2x2 + lambda*u with lambda = 1; returns [u, residual]."""
     lam = 1.0
     _track(x1, x2)
+    fused = _fused_second_order(fluid_model)
+    if fused is not None:
+        u, lin = fused(torch.cat((x1, x2), 1), 1.0, 1.0)
+        return [u, lin + lam * u]
     u = fluid_model(torch.cat((x1, x2), 1))
     _, u_11 = _second(u, x1)
     _, u_22 = _second(u, x2)

@@ -20,6 +20,7 @@ Any other model (the reference's duck type) runs the generic torch-autograd loop
 """
 from __future__ import annotations
 
+import os
 import time
 
 import torch
@@ -83,6 +84,7 @@ class FusedTrainer:
         self.model, self.device = model, dev
         self.eng = model._engine_for(dev)
         self.eng.sigma = (1.0, 1.0, 1.0)          # the trainers call the operator with its default scalings
+        self.eng.coeffs = None
         if pde:
             self.eng.D, self.eng.vx, self.eng.vy = float(pde["D"]), float(pde["vx"]), float(pde["vy"])
             self.eng.problem = int(pde["problem"])
@@ -115,6 +117,29 @@ class FusedTrainer:
             seed = int(t.item())
         self.fs.set_sampler(seed, shard_slice(batch_size, self.world, self.rank).start,
                             shard_slice(n3, self.world, self.rank).start, self.bc_start, self.bc_face_points)
+        # QC_DP_COLLECTIVE=rccl: the all-reduce runs INSIDE the library call (qc_comm_*: RCCL on the step's own stream,
+        # one host call per step); default: torch.distributed between the two phases
+        self._comm = None
+        if self.world > 1 and os.environ.get("QC_DP_COLLECTIVE", "torch") == "rccl":
+            self._comm = self._make_comm()
+            self.fs.set_comm(self._comm)
+
+    def _make_comm(self):
+        """One library-owned RCCL communicator over the ranks of the default process group (the 128-byte id travels
+        through torch.distributed once, at construction)."""
+        import ctypes as C
+        import torch.distributed as dist
+        lib = self.eng.lib
+        buf = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.check(lib.qc_comm_unique_id(buf), "qc_comm_unique_id")
+        t = torch.tensor(list(buf), dtype=torch.uint8, device=self.device)
+        dist.broadcast(t, 0)
+        raw = bytes(t.cpu().tolist())
+        comm = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.qc_comm_create(raw, self.world, self.rank, C.byref(comm)), "qc_comm_create")
+        return comm
 
     # -- optimiser state: continue from the torch optimiser / scheduler objects of the model
     def _make_opt_state(self, capacity):
@@ -197,7 +222,7 @@ class FusedTrainer:
 
     def step(self):
         draw = 0 if self._explicit else _lib.QC_PHASE_SAMPLE
-        if self.world == 1:
+        if self.world == 1 or self._comm is not None:
             self.fs.run(draw | _lib.QC_PHASE_GRADS | _lib.QC_PHASE_UPDATE)
         else:
             import torch.distributed as dist

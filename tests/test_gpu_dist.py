@@ -101,3 +101,43 @@ def test_bench_launches_its_own_ranks(gpu_device):
     assert out["config"]["per_gpu_batch"] == 131072 and out["config"]["global_batch"] == 262144   # config 4's shard
     assert out["value"] > 0 and np.isfinite(out["config"]["final_loss"])
     assert out["roofline"]["bound"] == "valu" and 0 < out["roofline"]["frac"] < 1
+
+
+def test_library_collective_single_rank(gpu_device, tmp_path):
+    """qc_comm_* / qc_allreduce_grads (RCCL behind the C ABI) on a one-rank communicator: the all-reduce is the
+    identity, and the fused step with the communicator in its descriptor (gradients -> all-reduce -> optimiser in ONE
+    library call) takes exactly the step it takes without it.  (More ranks need more GPUs than this box has.)"""
+    import ctypes as C
+    L = pkg("hip.lib")
+    lib = L.load()
+    ident = (C.c_ubyte * 128)()
+    L.check(lib.qc_comm_unique_id(ident), "qc_comm_unique_id")
+    comm = C.c_void_p()
+    with torch.cuda.device(gpu_device):
+        L.check(lib.qc_comm_create(bytes(ident), 1, 0, C.byref(comm)), "qc_comm_create")
+    try:
+        x = torch.randn(720, device=gpu_device)
+        y = x.clone()
+        st = torch.cuda.current_stream(gpu_device).cuda_stream
+        L.check(lib.qc_allreduce_grads(y.data_ptr(), y.numel(), comm, st), "qc_allreduce_grads")
+        torch.cuda.synchronize()
+        assert torch.equal(x, y)
+        Solver = pkg("nn.DVPDESolver").DVPDESolver
+        trainer = pkg("trainer.diffusion_train")
+        z = np.load(os.path.join(GOLDEN, "train_cascade_n4_b64.npz"))
+        hist = []
+        for use_comm in (False, True):
+            torch.manual_seed(1)
+            model = Solver(base_args(), Log(), device=gpu_device)
+            tr = trainer.FusedTrainer(model, 64, capacity=8)
+            if use_comm:
+                tr.fs.set_comm(comm)
+            for it in range(4):
+                tr.load_batches(*(torch.from_numpy(z[k][it]) for k in ("X_ic", "X_bc", "X_res")))
+                tr.fs.run(L.QC_PHASE_GRADS | L.QC_PHASE_UPDATE)
+            hist.append((np.array(tr.opt.loss_history()), model._flat.clone()))
+        assert np.abs(hist[0][0] - z["loss_history"][:4]).max() < 1e-4 * max(1.0, np.abs(z["loss_history"]).max())
+        assert np.array_equal(hist[0][0], hist[1][0])
+        assert (hist[0][1] - hist[1][1]).abs().max().item() < 1e-6     # fold+update in one kernel vs reduce, all-reduce, update
+    finally:
+        L.check(lib.qc_comm_destroy(comm), "qc_comm_destroy")

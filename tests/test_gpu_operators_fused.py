@@ -1,0 +1,83 @@
+"""Klein-Gordon, wave and Helmholtz operators (reference nn/pde.py:28-52,73-95) on a two-input DVPDESolver: second
+derivatives from the fused derivative-channel HIP kernels (``DVPDESolver.second_order``), checked against
+``tests/golden/other_operators.npz`` - outputs, loss and parameter gradient computed by the REFERENCE's own operator
+functions driving the CPU oracle (tests/golden/make_golden.py).  The fixture's model is Linear(2,16)-Tanh-Linear(16,4)
+-> <Z> -> Linear(4,16)-Tanh-Linear(16,1): exactly a DVPDESolver with classic_network [2, 16, 1]."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, pkg
+from test_gpu_solver import Log, base_args
+
+pytestmark = pytest.mark.gpu
+
+NAME_MAP = {"pre": "preprocessor", "post": "postprocessor", "q": "quantum_layer"}
+
+
+def _solver_from_fixture(z, name, device, tmp_path):
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    torch.manual_seed(0)
+    model = Solver(base_args(classic_network=[2, 16, 1]), Log(tmp_path), device=device)
+    prefix = f"{name}__w__"
+    sd = {}
+    for k in z.files:
+        if k.startswith(prefix):
+            parts = k[len(prefix):].split("__")
+            sd[".".join([NAME_MAP[parts[0]]] + parts[1:])] = torch.from_numpy(z[k])
+    with torch.no_grad():
+        for pname, p in model.named_parameters():
+            p.copy_(sd[pname].to(p.device))
+    return model, sd
+
+
+def _ref_grad(z, name, model):
+    """the fixture's gradient (composite order: pre, q, post) re-ordered to model.parameters() order"""
+    g = z[f"{name}__grad"]
+    shapes = {"pre.0.weight": (16, 2), "pre.0.bias": (16,), "pre.2.weight": (4, 16), "pre.2.bias": (4,), "q.params": (1, 12),
+              "post.0.weight": (16, 4), "post.0.bias": (16,), "post.2.weight": (1, 16), "post.2.bias": (1,)}
+    off, by = 0, {}
+    for k, shp in shapes.items():
+        n = int(np.prod(shp))
+        first, rest = k.split(".", 1)
+        by[NAME_MAP[first] + "." + rest] = g[off:off + n].reshape(shp)
+        off += n
+    assert off == g.size
+    return {n_: by[n_] for n_, _ in model.named_parameters()}
+
+
+@pytest.mark.parametrize("name", ["klein_gordon", "wave", "helmholtz"])
+def test_second_order_operators_on_fused_channels_match_reference(name, gpu_device, tmp_path):
+    z = np.load(os.path.join(GOLDEN, "other_operators.npz"))
+    pde = pkg("nn.pde")
+    model, _ = _solver_from_fixture(z, name, gpu_device, tmp_path)
+    assert model.preprocessor[0].weight.shape == (16, 2)          # the reference's parameter shapes
+    op = {"klein_gordon": pde.klein_gordon_operator, "wave": pde.wave_operator, "helmholtz": pde.helmholtz_operator}[name]
+    X = torch.from_numpy(z[f"{name}__X"]).to(gpu_device)
+    cols = [X[:, i:i + 1].clone() for i in range(2)]
+    res = list(op(model, *cols))
+    for i, r in enumerate(res):
+        want = z[f"{name}__out{i}"]
+        assert np.abs(r.detach().cpu().numpy() - want).max() < 1e-4 * max(1.0, np.abs(want).max()), (name, i)
+    loss = sum((r ** 2).mean() * (i + 1) for i, r in enumerate(res))
+    assert abs(loss.item() - float(z[f"{name}__loss"])) < 1e-4 * max(1.0, float(z[f"{name}__loss"]))
+    model.zero_grad()
+    loss.backward()
+    ref = _ref_grad(z, name, model)
+    gs = max(1.0, max(np.abs(v).max() for v in ref.values()))
+    for pname, p in model.named_parameters():
+        assert np.abs(p.grad.cpu().numpy() - ref[pname]).max() < 2e-4 * gs, pname
+    # the value path of the two-input model agrees with the operator's u
+    with torch.no_grad():
+        assert (model(X) - res[0]).abs().max().item() < 1e-6
+
+
+def test_two_input_model_refuses_three_columns(gpu_device, tmp_path):
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    model = Solver(base_args(classic_network=[2, 16, 1]), Log(tmp_path), device=gpu_device)
+    with pytest.raises(ValueError):
+        model(torch.rand(4, 3, device=gpu_device))
+    with pytest.raises(ValueError):
+        model.residual(torch.rand(4, 3, device=gpu_device))
