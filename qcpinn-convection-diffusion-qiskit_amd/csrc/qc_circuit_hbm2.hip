@@ -193,11 +193,9 @@ __device__ __forceinline__ void g_x(SV<N>& v) {
 #pragma unroll
   for (int k = 0; k < (1 << (N - 1)); ++k) {
     const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
-    const float ar = v.re[i0], ai = v.im[i0];
-    v.re[i0] = v.re[i1];
-    v.im[i0] = v.im[i1];
-    v.re[i1] = ar;
-    v.im[i1] = ai;
+    const qf2 a = v.a[i0];
+    v.a[i0] = v.a[i1];
+    v.a[i1] = a;
   }
 }
 
@@ -213,14 +211,14 @@ __device__ __forceinline__ void h2_apply_x(SV<N> (&v)[K], int tq) {
   }
 }
 
-template <int N, int K>
-__device__ __forceinline__ void h2_apply_u4(SV<N> (&v)[K], int hq, int lq, const float* __restrict__ u) {
+template <int N, int K, class UP>
+__device__ __forceinline__ void h2_apply_u4(SV<N> (&v)[K], int hq, int lq, UP u) {
   if constexpr (N >= 2) {
     switch (hq * 4 + lq) {
 #define HU_(HB, LB)                                                                       \
   case (HB * 4 + LB):                                                                     \
     if constexpr (HB < N && LB < N && HB != LB) {                                         \
-      _Pragma("unroll") for (int q = 0; q < K; ++q) g_u4<N, HB, LB>(v[q], u);             \
+      _Pragma("unroll") for (int q = 0; q < K; ++q) g_u4<N, HB, LB, UP>(v[q], u);         \
     }                                                                                     \
     asm volatile("" ::"n"(HB * 4 + LB));                                                  \
     break;
@@ -598,8 +596,8 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           for (int q = 0; q < R; ++q) {
             const int a = alane | dr[q];
             const Cplx x = gen ? gen_amp(c, lbase | roff[q], a) : g[a];
-            v[0].re[q] = x.re;
-            v[0].im[q] = x.im;
+            v[0].a[q].x = x.re;
+            v[0].a[q].y = x.im;
           }
         } else {
           const Cplx* g = chi_of(c);
@@ -612,10 +610,10 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             Cplx y;
             if (LASTC && A.last) y = build_lam(c, lbase | roff[q], x, c == 0 ? x : g0[a], l0acc[LASTC ? q : 0]);
             else y = gl[a];
-            v[0].re[q] = x.re;
-            v[0].im[q] = x.im;
-            v[1].re[q] = y.re;
-            v[1].im[q] = y.im;
+            v[0].a[q].x = x.re;
+            v[0].a[q].y = x.im;
+            v[1].a[q].x = y.re;
+            v[1].a[q].y = y.im;
           }
         }
       } else {
@@ -623,12 +621,12 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
         for (int q = 0; q < R; ++q) {
           const int li = sl ^ sr[q];
           const Cplx x = t0[li];
-          v[0].re[q] = x.re;
-          v[0].im[q] = x.im;
+          v[0].a[q].x = x.re;
+          v[0].a[q].y = x.im;
           if constexpr (BWD) {
             const Cplx y = t1[li];
-            v[1].re[q] = y.re;
-            v[1].im[q] = y.im;
+            v[1].a[q].x = y.re;
+            v[1].a[q].y = y.im;
           }
         }
       }
@@ -640,21 +638,16 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
         for (int q = 0; q < R; ++q) {
           const Cplx ph = tab[alane | dr[q]];
           if constexpr (!BWD) {
-            const Cplx x = cmul({v[0].re[q], v[0].im[q]}, ph);
-            v[0].re[q] = x.re;
-            v[0].im[q] = x.im;
+            v[0].a[q] = qc_cmul(ph.re, ph.im, v[0].a[q]);
           } else {
-            const float tv = v[1].re[q] * v[0].im[q] - v[1].im[q] * v[0].re[q];
+            const qf2 m = v[1].a[q] * qc_swp(v[0].a[q]);   // Im(conj(lam) chi) = lo - hi
+            const float tv = m.x - m.y;
             if constexpr (TABC) {
               if (tslot == 0) tacc0[q] += tv;
               else tacc1[q] += tv;
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-              const Cplx x = cmulc({v[k].re[q], v[k].im[q]}, ph);
-              v[k].re[q] = x.re;
-              v[k].im[q] = x.im;
-            }
+            for (int k = 0; k < 2; ++k) v[k].a[q] = qc_cmul(ph.re, -ph.im, v[k].a[q]);
           }
         }
       };
@@ -714,25 +707,21 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
               const bool on = hg.cbit < 0 || ((a >> hg.cbit) & 1);
               const bool hi = (a >> hg.tbit) & 1;
               if constexpr (BWD) {
-                const float tv = v[1].re[q] * v[0].im[q] - v[1].im[q] * v[0].re[q];
+                const qf2 m = v[1].a[q] * qc_swp(v[0].a[q]);
+                const float tv = m.x - m.y;
                 grad += on ? (hi ? -tv : tv) : 0.f;
               }
               const float sq = on ? (hi ? sg : -sg) : 0.f, cq = on ? c_ : 1.f;   // multiply by cq + i sq
 #pragma unroll
-              for (int k = 0; k < KV; ++k) {
-                const float ar = v[k].re[q], ai = v[k].im[q];
-                v[k].re[q] = cq * ar - sq * ai;
-                v[k].im[q] = cq * ai + sq * ar;
-              }
+              for (int k = 0; k < KV; ++k) v[k].a[q] = qc_cmul(cq, sq, v[k].a[q]);
             }
             break;
           }
           case H2_K_U4: {
-            float us[32];   // the 4x4 matrix in SGPRs
+            // the 4x4 matrix through the constant address space: (re, im) records as SGPR pairs, fetched inside the one
+            // (high, low) arm that runs (32 SGPRs held across the switch would spill the interpreter's scalar state)
             const auto* um = h2_const(A.umat + (hg.slot * 2 + (BWD ? 1 : 0)) * 32);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) us[i] = um[i];
-            h2_apply_u4<RB, KV>(v, hg.tq, hg.cq, us);
+            h2_apply_u4<RB, KV>(v, hg.tq, hg.cq, um);
             break;
           }
           default: break;
@@ -753,7 +742,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           if (LASTC && A.last) {
             Cplx fin[R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) fin[q] = {v[0].re[q], v[0].im[q]};
+            for (int q = 0; q < R; ++q) fin[q] = {v[0].a[q].x, v[0].a[q].y};
             int rbp[RB];
 #pragma unroll
             for (int j = 0; j < RB; ++j) rbp[j] = rd.rb[j];
@@ -762,23 +751,23 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           if (!(LASTC && A.last) || A.keep_final) {
             Cplx* g = chi_of(c);
 #pragma unroll
-            for (int q = 0; q < R; ++q) g[alane | dr[q]] = {v[0].re[q], v[0].im[q]};
+            for (int q = 0; q < R; ++q) g[alane | dr[q]] = {v[0].a[q].x, v[0].a[q].y};
           }
         } else {
           Cplx* g = chi_of(c);
           Cplx* gl = lam_of(c);
 #pragma unroll
           for (int q = 0; q < R; ++q) {
-            g[alane | dr[q]] = {v[0].re[q], v[0].im[q]};
-            gl[alane | dr[q]] = {v[1].re[q], v[1].im[q]};
+            g[alane | dr[q]] = {v[0].a[q].x, v[0].a[q].y};
+            gl[alane | dr[q]] = {v[1].a[q].x, v[1].a[q].y};
           }
         }
       } else {
 #pragma unroll
         for (int q = 0; q < R; ++q) {
           const int li = sl ^ sr[q];
-          t0[li] = {v[0].re[q], v[0].im[q]};
-          if constexpr (BWD) t1[li] = {v[1].re[q], v[1].im[q]};
+          t0[li] = {v[0].a[q].x, v[0].a[q].y};
+          if constexpr (BWD) t1[li] = {v[1].a[q].x, v[1].a[q].y};
         }
         H2_SYNC();
       }
@@ -828,8 +817,8 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
 #pragma unroll
             for (int q = 0; q < R; ++q) {
               const Cplx y = t1[sl2 ^ h2_swz<RB>(q << (grp * RB))];
-              u[0].re[q] = y.re;
-              u[0].im[q] = y.im;
+              u[0].a[q].x = y.re;
+              u[0].a[q].y = y.im;
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
@@ -842,7 +831,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
               qc_apply_gate<RB, 1, true>(u, gg, h2_unif(w8[0]), h2_unif(w8[1]), A.umat);
             }
 #pragma unroll
-            for (int q = 0; q < R; ++q) t1[sl2 ^ h2_swz<RB>(q << (grp * RB))] = {u[0].re[q], u[0].im[q]};
+            for (int q = 0; q < R; ++q) t1[sl2 ^ h2_swz<RB>(q << (grp * RB))] = {u[0].a[q].x, u[0].a[q].y};
             H2_SYNC();
           }
           Cplx* xo = A.xi + (((size_t)c * A.pt_stride + pt) * ntau + tau) * A.nx;

@@ -136,29 +136,29 @@ struct StatProg {
     const QcTrig* tab = trig + SP::G + run_ordinal(I) * (1 << N);
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
-      const float dr = tab[k].c, di = ADJ ? -tab[k].s : tab[k].s;
+      const float dr = tab[k].c, di = ADJ ? -tab[k].s : tab[k].s;   // adjacent in the table: one SGPR pair
 #pragma unroll
-      for (int q = 0; q < K; ++q) {
-        const float ar = v[q].re[k], ai = v[q].im[k];
-        v[q].re[k] = fmaf(-di, ai, dr * ar);
-        v[q].im[k] = fmaf(di, ar, dr * ai);
-      }
+      for (int q = 0; q < K; ++q) v[q].a[k] = qc_cmul(dr, di, v[q].a[k]);
     }
   }
   // gradient terms of the gates H, H+1, ..., E-1 of one run from t[k] = Im(conj(lam_k) chi_k) (invariant under
   // the other diagonal gates of the run): signed by the target bit, masked by the control bit
   template <int H, int E>
-  __device__ static __forceinline__ void run_grads(const float (&t)[1 << N], float (&gacc)[SP::P > 0 ? SP::P : 1]) {
+  __device__ static __forceinline__ void run_grads(const QcPk<(1 << N)>& t, float (&gacc)[SP::P > 0 ? SP::P : 1]) {
     if constexpr (H < E) {
       constexpr SGate g = SP::g[H];
       constexpr bool ctl = g.op == QC_CRZ;
       constexpr int tb = ctl ? g.bb : g.ba;
-      float acc = 0.f;
+      constexpr int cb = ctl ? g.ba : -1;
+      qf2 a2 = {0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < (1 << N); ++k) {
-        if (ctl && !((k >> g.ba) & 1)) continue;
-        acc += ((k >> tb) & 1) ? -t[k] : t[k];
+      for (int j = 0; j < (1 << (N - 1)); ++j) {
+        if (cb >= 1 && !((j >> (cb >= 1 ? cb - 1 : 0)) & 1)) continue;
+        if (tb >= 1 && ((j >> (tb >= 1 ? tb - 1 : 0)) & 1)) a2 -= t.p[j];
+        else a2 += t.p[j];
       }
+      // target on bit 0: the halves carry opposite signs; control on bit 0: only the upper halves count
+      const float acc = tb == 0 ? a2.x - a2.y : (cb == 0 ? a2.y : a2.x + a2.y);
       if constexpr (g.slot >= 0) gacc[g.slot] += qc_wave_sum_to_lane63(acc);
       run_grads<H + 1, E>(t, gacc);
     }
@@ -206,9 +206,12 @@ struct StatProg {
     }
     if constexpr (fused(I)) {
       if constexpr (I == run_end(I) - 1) {   // first gate of the run met by the reverse sweep
-        float tk[1 << N];
+        QcPk<(1 << N)> tk;   // Im(conj(lam_k) chi_k), two k per pair for the signed sums
 #pragma unroll
-        for (int k = 0; k < (1 << N); ++k) tk[k] = cl[1].re[k] * cl[0].im[k] - cl[1].im[k] * cl[0].re[k];
+        for (int k = 0; k < (1 << N); ++k) {
+          const qf2 m = cl[1].a[k] * qc_swp(cl[0].a[k]);
+          tk[k] = m.x - m.y;
+        }
         run_grads<run_begin(I), run_end(I)>(tk, gacc);
         apply_table<I, true, 2>(cl, trig);
         __builtin_amdgcn_sched_barrier(0);
@@ -268,7 +271,7 @@ __device__ __forceinline__ void load_sincos(float (&ca)[N], float (&sa)[N], cons
 // Embedding series of channel `ch`'s direction for this lane's point: P0 = phi, P1 = d phi,
 // P2 = d2 phi (only as far as the channel needs).
 template <int N>
-__device__ __forceinline__ void channel_series(float (&P0)[1 << N], float (&P1)[1 << N], float (&P2)[1 << N],
+__device__ __forceinline__ void channel_series(QcPk<(1 << N)>& P0, QcPk<(1 << N)>& P1, QcPk<(1 << N)>& P2,
                                                int ch, const float* __restrict__ ajets, int64_t B, int64_t pc,
                                                const QcTrig* __restrict__ trig, int absorb, const float* cs = nullptr) {
   float ca[N], sa[N], da[N], dda[N];
@@ -293,12 +296,12 @@ __device__ __forceinline__ void build_channel(SV<N>& v, int ch, const float* __r
   if (amp) {
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
-      v.re[k] = k < N ? ajets[((int64_t)ch * N + k) * B + pc] : 0.f;
-      v.im[k] = 0.f;
+      v.a[k].x = k < N ? ajets[((int64_t)ch * N + k) * B + pc] : 0.f;
+      v.a[k].y = 0.f;
     }
     return;
   }
-  float P0[1 << N], P1[1 << N], P2[1 << N];
+  QcPk<(1 << N)> P0, P1, P2;
   channel_series<N>(P0, P1, P2, ch, ajets, B, pc, trig, absorb, cs);
   if (ch == 0) qc_phase_load<N>(v, P0);
   else if (ch <= 3) qc_phase_load<N>(v, P1);
@@ -324,9 +327,13 @@ __device__ __forceinline__ void k_value_fwd_body(const int64_t bid, const QcGate
   SV<N> v[1];
   build_channel<N>(v[0], 0, angles, B, pc, amp & 1, trig, amp >> 1);
   PG::fwd(v, prog, trig, umat, n_gates, amp >> 1);
-  float t[1 << N], q[N];
+  QcPk<(1 << N)> t;
+  float q[N];
 #pragma unroll
-  for (int k = 0; k < (1 << N); ++k) t[k] = v[0].re[k] * v[0].re[k] + v[0].im[k] * v[0].im[k];
+  for (int k = 0; k < (1 << N); ++k) {
+    const qf2 m = v[0].a[k] * v[0].a[k];
+    t[k] = m.x + m.y;
+  }
   qc_signed_sums<N>(q, t);
   if (p < B) {
 #pragma unroll
@@ -367,21 +374,19 @@ __device__ __forceinline__ void k_value_bwd_body(const int64_t bid, const QcGate
   float qb[N];
 #pragma unroll
   for (int w = 0; w < N; ++w) qb[w] = live ? cot[(int64_t)w * B + pc] : 0.f;
+  {
+    QcPk<(1 << N)> d;
+    qc_sign_sums<N>(d, qb);
 #pragma unroll
-  for (int k = 0; k < (1 << N); ++k) {
-    float d = 0.f;
-#pragma unroll
-    for (int w = 0; w < N; ++w) d += ((k >> (N - 1 - w)) & 1) ? -qb[w] : qb[w];
-    cl[1].re[k] = d * cl[0].re[k];
-    cl[1].im[k] = d * cl[0].im[k];
+    for (int k = 0; k < (1 << N); ++k) cl[1].a[k] = qc_dup(d[k]) * cl[0].a[k];
   }
   PG::bwd(cl, prog, trig, umat, n_gates, smem + wave * n_params, lane, amp >> 1);
   float T[N];
   if (amp & 1) {   // d L / d(initial amplitude k) = 2 Re Lambda_k  (the initial amplitudes are real)
 #pragma unroll
-    for (int w = 0; w < N; ++w) T[w] = 2.f * cl[1].re[w];
+    for (int w = 0; w < N; ++w) T[w] = 2.f * cl[1].a[w].x;
   } else {
-    float Q0[1 << N], Q1[1 << N], Q2[1 << N];
+    QcPk<(1 << N)> Q0, Q1, Q2;
     channel_series<N>(Q0, Q1, Q2, 0, qc_launder(angles), B, pc, trig, amp >> 1);
     qc_embed_ip<N>(T, cl[1], Q0);
   }
@@ -414,9 +419,23 @@ __global__ void __launch_bounds__(256) k_value_bwd(const QcGate* __restrict__ pr
 
 // Final-state store handed from k_jets_fwd to k_jets_bwd: tile-major, so the 6 x A2 x 64 floats one
 // block touches are one contiguous 6*A2*256-byte region (DRAM-page friendly), not A2 streams B apart.
+// Units are amplitudes = (re, im) register pairs: 8 bytes per lane, one global_load/store_dwordx2 = 512 contiguous
+// bytes per wave.
 template <int A2>
-__device__ __forceinline__ int64_t qc_chi_index(int ch, int k2, int64_t p) {
-  return ((((p >> 6) * 6 + ch) * A2 + k2) << 6) | (p & 63);
+__device__ __forceinline__ int64_t qc_chi_pair(int ch, int k, int64_t p) {
+  return ((((p >> 6) * 6 + ch) * (A2 / 2) + k) << 6) | (p & 63);
+}
+template <int N>
+__device__ __forceinline__ void qc_chi_write(float* __restrict__ chi_store, int ch, int64_t p, const SV<N>& v) {
+  qf2* cs = reinterpret_cast<qf2*>(chi_store);
+#pragma unroll
+  for (int k = 0; k < (1 << N); ++k) cs[qc_chi_pair<(2 << N)>(ch, k, p)] = v.a[k];
+}
+template <int N>
+__device__ __forceinline__ void qc_chi_read(SV<N>& v, const float* __restrict__ chi_store, int ch, int64_t p) {
+  const qf2* cs = reinterpret_cast<const qf2*>(chi_store);
+#pragma unroll
+  for (int k = 0; k < (1 << N); ++k) v.a[k] = cs[qc_chi_pair<(2 << N)>(ch, k, p)];
 }
 
 // ================================================================== six derivative channels
@@ -442,38 +461,39 @@ __device__ __forceinline__ void k_jets_fwd_body(const int64_t bid, const QcGate*
   SV<N> v[1];
   build_channel<N>(v[0], ch, ajets, B, pc, amp & 1, trig, amp >> 1, s_cs);
   PG::fwd(v, prog, trig, umat, n_gates, amp >> 1);
-  if (chi_store != nullptr && p < B) {   // final states for the adjoint kernel of the same step: [6][A2][B]
-#pragma unroll
-    for (int k = 0; k < (1 << N); ++k) {
-      chi_store[qc_chi_index<A2>(ch, 2 * k, p)] = v[0].re[k];
-      chi_store[qc_chi_index<A2>(ch, 2 * k + 1, p)] = v[0].im[k];
-    }
-  }
+  if (chi_store != nullptr && p < B) qc_chi_write<N>(chi_store, ch, p, v[0]);   // final states for the adjoint kernel
 
-  float t[1 << N], q[N];
+  QcPk<(1 << N)> t;
+  float q[N];
+  qf2* s_x0 = reinterpret_cast<qf2*>(s_chi0);   // [amplitude][lane]
   if (ch == 0) {
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
-      s_chi0[(2 * k) * 64 + lane] = v[0].re[k];
-      s_chi0[(2 * k + 1) * 64 + lane] = v[0].im[k];
-      t[k] = v[0].re[k] * v[0].re[k] + v[0].im[k] * v[0].im[k];
+      s_x0[k * 64 + lane] = v[0].a[k];
+      const qf2 m = v[0].a[k] * v[0].a[k];
+      t[k] = m.x + m.y;
     }
     qc_signed_sums<N>(q, t);
   } else if (ch == 2 || ch == 3) {
 #pragma unroll
-    for (int k = 0; k < (1 << N); ++k) t[k] = 2.f * (v[0].re[k] * v[0].re[k] + v[0].im[k] * v[0].im[k]);
+    for (int k = 0; k < (1 << N); ++k) {
+      const qf2 m = v[0].a[k] * v[0].a[k];
+      t[k] = m.x + m.y;
+    }
     qc_signed_sums<N>(q, t);
 #pragma unroll
-    for (int w = 0; w < N; ++w) s_sq[((ch - 2) * N + w) * 64 + lane] = q[w];
+    for (int w = 0; w < N; ++w) s_sq[((ch - 2) * N + w) * 64 + lane] = 2.f * q[w];
   }
   __syncthreads();
   if (ch != 0) {
 #pragma unroll
     for (int k = 0; k < (1 << N); ++k) {
-      const float r0 = s_chi0[(2 * k) * 64 + lane], i0 = s_chi0[(2 * k + 1) * 64 + lane];
-      t[k] = 2.f * (r0 * v[0].re[k] + i0 * v[0].im[k]);
+      const qf2 m = s_x0[k * 64 + lane] * v[0].a[k];   // Re(conj(chi_0) chi_c)
+      t[k] = m.x + m.y;
     }
     qc_signed_sums<N>(q, t);
+#pragma unroll
+    for (int w = 0; w < N; ++w) q[w] *= 2.f;
     if (ch >= 4) {
 #pragma unroll
       for (int w = 0; w < N; ++w) q[w] += s_sq[((ch - 4) * N + w) * 64 + lane];
@@ -525,11 +545,7 @@ __device__ __forceinline__ void k_jets_bwd_body(const int64_t bid, const QcGate*
 
   SV<N> cl[2];
   if constexpr (LOAD) {
-#pragma unroll
-    for (int k = 0; k < (1 << N); ++k) {
-      cl[0].re[k] = chi_store[qc_chi_index<A2>(ch, 2 * k, pc)];
-      cl[0].im[k] = chi_store[qc_chi_index<A2>(ch, 2 * k + 1, pc)];
-    }
+    qc_chi_read<N>(cl[0], chi_store, ch, pc);
   } else {
     SV<N> v[1];
     build_channel<N>(v[0], ch, ajets, B, pc, amp & 1, trig, amp >> 1);
@@ -540,65 +556,43 @@ __device__ __forceinline__ void k_jets_bwd_body(const int64_t bid, const QcGate*
   // forward kernel's store (L2-resident) when LOAD -- then no exchange buffer and no barrier is needed
   // before the sweep, and the block's LDS shrinks to the small tail buffers.
   if constexpr (!LOAD) {
-    float* mine = s_chi + ch * A2 * 64;
+    qf2* mine = reinterpret_cast<qf2*>(s_chi) + ch * (A2 / 2) * 64;
 #pragma unroll
-    for (int k = 0; k < (1 << N); ++k) {
-      mine[(2 * k) * 64 + lane] = cl[0].re[k];
-      mine[(2 * k + 1) * 64 + lane] = cl[0].im[k];
-    }
+    for (int k = 0; k < (1 << N); ++k) mine[k * 64 + lane] = cl[0].a[k];
     __syncthreads();
   }
-  auto other_re = [&](int c, int k) {
-    return LOAD ? chi_store[qc_chi_index<A2>(c, 2 * k, pc)] : s_chi[(c * A2 + 2 * k) * 64 + lane];
-  };
-  auto other_im = [&](int c, int k) {
-    return LOAD ? chi_store[qc_chi_index<A2>(c, 2 * k + 1, pc)] : s_chi[(c * A2 + 2 * k + 1) * 64 + lane];
+  // amplitude k of channel c's final state
+  auto other = [&](int c, int k) -> qf2 {
+    return LOAD ? reinterpret_cast<const qf2*>(chi_store)[qc_chi_pair<A2>(c, k, pc)]
+                : reinterpret_cast<const qf2*>(s_chi)[(c * (A2 / 2) + k) * 64 + lane];
   };
 
   // ---- cotangent of this channel's final state (bilinear <Z> forms)
-  auto dvec = [&](int c, float (&d)[1 << N]) {
+  auto dvec = [&](int c, QcPk<(1 << N)>& d) {
     float qb[N];
 #pragma unroll
     for (int w = 0; w < N; ++w) qb[w] = live ? qbar[((int64_t)c * N + w) * B + pc] : 0.f;
-#pragma unroll
-    for (int k = 0; k < (1 << N); ++k) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < N; ++w) s += ((k >> (N - 1 - w)) & 1) ? -qb[w] : qb[w];
-      d[k] = s;
-    }
+    qc_sign_sums<N>(d, qb);
   };
-  float d[1 << N];
+  QcPk<(1 << N)> d;
   if (ch == 0) {
     dvec(0, d);
 #pragma unroll
-    for (int k = 0; k < (1 << N); ++k) {
-      cl[1].re[k] = d[k] * cl[0].re[k];
-      cl[1].im[k] = d[k] * cl[0].im[k];
-    }
+    for (int k = 0; k < (1 << N); ++k) cl[1].a[k] = qc_dup(d[k]) * cl[0].a[k];
 #pragma unroll 1
     for (int c = 1; c < QC_NCH; ++c) {   // one channel at a time: keeps the live set at one vector
       dvec(c, d);
 #pragma unroll
-      for (int k = 0; k < (1 << N); ++k) {
-        cl[1].re[k] = fmaf(d[k], other_re(c, k), cl[1].re[k]);
-        cl[1].im[k] = fmaf(d[k], other_im(c, k), cl[1].im[k]);
-      }
+      for (int k = 0; k < (1 << N); ++k) cl[1].a[k] = qc_pk_fma(qc_dup(d[k]), other(c, k), cl[1].a[k]);
     }
   } else {
     dvec(ch, d);
 #pragma unroll
-    for (int k = 0; k < (1 << N); ++k) {
-      cl[1].re[k] = d[k] * other_re(0, k);
-      cl[1].im[k] = d[k] * other_im(0, k);
-    }
+    for (int k = 0; k < (1 << N); ++k) cl[1].a[k] = qc_dup(d[k]) * other(0, k);
     if (ch == 2 || ch == 3) {
       dvec(ch + 2, d);
 #pragma unroll
-      for (int k = 0; k < (1 << N); ++k) {
-        cl[1].re[k] = fmaf(2.f * d[k], cl[0].re[k], cl[1].re[k]);
-        cl[1].im[k] = fmaf(2.f * d[k], cl[0].im[k], cl[1].im[k]);
-      }
+      for (int k = 0; k < (1 << N); ++k) cl[1].a[k] = qc_pk_fma(qc_dup(2.f * d[k]), cl[0].a[k], cl[1].a[k]);
     }
   }
   if constexpr (!LOAD) __syncthreads();  // everyone is done reading s_chi
@@ -610,7 +604,7 @@ __device__ __forceinline__ void k_jets_bwd_body(const int64_t bid, const QcGate*
     // the swept lambda directly: d L / d u_c[k] = 2 Re Lambda_c[k] (no coupling between channels here)
     if (live) {
 #pragma unroll
-      for (int w = 0; w < N; ++w) abar[((int64_t)ch * N + w) * B + p] = 2.f * cl[1].re[w];
+      for (int w = 0; w < N; ++w) abar[((int64_t)ch * N + w) * B + p] = 2.f * cl[1].a[w].x;
     }
     __syncthreads();
   } else {
@@ -731,35 +725,24 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
   const int cha = wv == 0 ? 1 : wv + 1;        // first channel of this wave: t, x, y
   const int chb = wv == 0 ? 0 : wv + 3;        // second: value, xx, yy
 
-  auto load_chi = [&](SV<N>& v, int c) {
-    const int64_t pq = pcf();
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      v.re[k] = chi_store[qc_chi_index<A2>(c, 2 * k, pq)];
-      v.im[k] = chi_store[qc_chi_index<A2>(c, 2 * k + 1, pq)];
-    }
-  };
-  auto dvec = [&](int c, float (&d)[NA]) {
+  const qf2* chi2 = reinterpret_cast<const qf2*>(chi_store);
+  qf2* s_l02 = reinterpret_cast<qf2*>(s_l0);     // [3 waves][amplitude][64]
+  auto load_chi = [&](SV<N>& v, int c) { qc_chi_read<N>(v, chi_store, c, pcf()); };
+  auto dvec = [&](int c, QcPk<NA>& d) {
     float qb[N];
     const int64_t pq = pcf();
 #pragma unroll
     for (int w = 0; w < N; ++w) qb[w] = live ? qbar[((int64_t)c * N + w) * B + pq] : 0.f;
-#pragma unroll
-    for (int k = 0; k < NA; ++k) {
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < N; ++w) s += ((k >> (N - 1 - w)) & 1) ? -qb[w] : qb[w];
-      d[k] = s;
-    }
+    qc_sign_sums<N>(d, qb);
   };
 
   SV<N> cl[2];
-  float d[NA];
+  QcPk<NA> d;
   {
     // this wave's share of lam_0 = sum_c D_c chi_c (to LDS), and lam of its first channel; the second channel's final
     // state and chi_0 stream through (they are reloaded when their turn comes) to keep the live set at two vectors
-    float da_[NA];
-    float* mine = s_l0 + wv * A2 * 64;
+    QcPk<NA> da_;
+    qf2* mine = s_l02 + wv * NA * 64;
     load_chi(cl[0], cha);
     dvec(cha, da_);
     dvec(chb, d);
@@ -767,25 +750,17 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
       load_chi(cl[1], 0);
 #pragma unroll
       for (int k = 0; k < NA; ++k) {
-        mine[(2 * k) * 64 + lane] = fmaf(da_[k], cl[0].re[k], d[k] * cl[1].re[k]);
-        mine[(2 * k + 1) * 64 + lane] = fmaf(da_[k], cl[0].im[k], d[k] * cl[1].im[k]);
-        cl[1].re[k] *= da_[k];
-        cl[1].im[k] *= da_[k];
+        mine[k * 64 + lane] = qc_pk_fma(qc_dup(da_[k]), cl[0].a[k], qc_dup(d[k]) * cl[1].a[k]);
+        cl[1].a[k] *= qc_dup(da_[k]);
       }
     } else {                  // lam_x = D_x chi_0 + 2 D_xx chi_x (the same for y)
       const int64_t pq = pcf();
 #pragma unroll
-      for (int k = 0; k < NA; ++k) {
-        const float br = chi_store[qc_chi_index<A2>(chb, 2 * k, pq)], bi = chi_store[qc_chi_index<A2>(chb, 2 * k + 1, pq)];
-        mine[(2 * k) * 64 + lane] = fmaf(da_[k], cl[0].re[k], d[k] * br);
-        mine[(2 * k + 1) * 64 + lane] = fmaf(da_[k], cl[0].im[k], d[k] * bi);
-      }
+      for (int k = 0; k < NA; ++k)
+        mine[k * 64 + lane] = qc_pk_fma(qc_dup(da_[k]), cl[0].a[k], qc_dup(d[k]) * chi2[qc_chi_pair<A2>(chb, k, pq)]);
 #pragma unroll
-      for (int k = 0; k < NA; ++k) {
-        const float x0r = chi_store[qc_chi_index<A2>(0, 2 * k, pq)], x0i = chi_store[qc_chi_index<A2>(0, 2 * k + 1, pq)];
-        cl[1].re[k] = fmaf(2.f * d[k], cl[0].re[k], da_[k] * x0r);
-        cl[1].im[k] = fmaf(2.f * d[k], cl[0].im[k], da_[k] * x0i);
-      }
+      for (int k = 0; k < NA; ++k)
+        cl[1].a[k] = qc_pk_fma(qc_dup(2.f * d[k]), cl[0].a[k], qc_dup(da_[k]) * chi2[qc_chi_pair<A2>(0, k, pq)]);
     }
   }
   __syncthreads();   // shares of lam_0, s_cs, s_acc
@@ -803,18 +778,13 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
       load_chi(cl[0], chb);
       if (wv == 0) {          // lam_0: the three shares
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-          cl[1].re[k] = (s_l0[(2 * k) * 64 + lane] + s_l0[(A2 + 2 * k) * 64 + lane]) + s_l0[(2 * A2 + 2 * k) * 64 + lane];
-          cl[1].im[k] = (s_l0[(2 * k + 1) * 64 + lane] + s_l0[(A2 + 2 * k + 1) * 64 + lane]) + s_l0[(2 * A2 + 2 * k + 1) * 64 + lane];
-        }
+        for (int k = 0; k < NA; ++k)
+          cl[1].a[k] = (s_l02[k * 64 + lane] + s_l02[(NA + k) * 64 + lane]) + s_l02[(2 * NA + k) * 64 + lane];
       } else {                // lam_xx = D_xx chi_0
         dvec(chb, d);
         const int64_t pq = pcf();
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {
-          cl[1].re[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k, pq)];
-          cl[1].im[k] = d[k] * chi_store[qc_chi_index<A2>(0, 2 * k + 1, pq)];
-        }
+        for (int k = 0; k < NA; ++k) cl[1].a[k] = qc_dup(d[k]) * chi2[qc_chi_pair<A2>(0, k, pq)];
       }
     }
     PG::bwd(cl, prog, trig, umat, n_gates, s_acc + wv * n_params, lane, amp >> 1);

@@ -12,10 +12,53 @@
 #pragma once
 #include "qc_common.h"
 
+// ---- packed fp32 arithmetic.
+// The gfx950 VALU issues a wave64 v_fma_f32 in 4 cycles and a v_pk_fma_f32 (two fp32 lanes per 64-bit register pair)
+// in the same 4 (MI355X_MICROARCH.md, per-instruction cycle constants): scalar fp32 code tops out at HALF the 157 TF
+// vector peak.  An amplitude is therefore ONE register pair (re, im), and every gate update is written on pairs:
+//   (x + i y)(a)      = x a + {-y, y} swap(a)        (swap = the two halves exchanged: an op_sel modifier, free)
+//   Im(conj(l) a)     = lo - hi of l * swap(a)
+// so a complex multiply-add is 2 packed instructions instead of 4 scalar ones, whatever bit the gate acts on; the
+// (cos, sin) / (re, im) coefficient pairs of the trig and Haar tables are adjacent in memory and reach the packed
+// instructions as SGPR pairs with broadcast / negate modifiers (no repacking).  The layout is also the (re, im)
+// record of the statevectors in LDS and HBM (n >= 9 family, final-state hand-off), so loads and stores are 64-bit.
+typedef float qf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ qf2 qc_swp(const qf2 a) { return __builtin_shufflevector(a, a, 1, 0); }
+__device__ __forceinline__ qf2 qc_dup(const float a) { return (qf2){a, a}; }
+__device__ __forceinline__ qf2 qc_pm(const float a) { return (qf2){a, -a}; }     // {a, -a}
+__device__ __forceinline__ qf2 qc_mp(const float a) { return (qf2){-a, a}; }     // {-a, a}
+__device__ __forceinline__ qf2 qc_pk_fma(const qf2 a, const qf2 b, const qf2 c) { return __builtin_elementwise_fma(a, b, c); }
+// z * a for z = x + i y
+__device__ __forceinline__ qf2 qc_cmul(const float x, const float y, const qf2 a) { return qc_pk_fma(qc_mp(y), qc_swp(a), qc_dup(x) * a); }
+// acc + z * a
+__device__ __forceinline__ qf2 qc_cfma(const float x, const float y, const qf2 a, const qf2 acc) {
+  return qc_pk_fma(qc_mp(y), qc_swp(a), qc_pk_fma(qc_dup(x), a, acc));
+}
+
+// M real numbers as M/2 register pairs (embedding magnitudes, diagonals, probabilities); element k = half (k & 1) of
+// pair k >> 1.  operator[] keeps element-wise code (compile-time indices after unrolling) readable.
+template <int M>
+struct QcPk {
+  static_assert(M >= 2 && M % 2 == 0, "packed arrays hold an even number of floats");
+  qf2 p[M / 2];
+  struct Ref {
+    qf2& q;
+    const int h;
+    __device__ __forceinline__ operator float() const { return h ? q.y : q.x; }
+    __device__ __forceinline__ Ref& operator=(const float x) {
+      if (h) q.y = x;
+      else q.x = x;
+      return *this;
+    }
+    __device__ __forceinline__ Ref& operator=(const Ref& o) { return *this = (float)o; }
+  };
+  __device__ __forceinline__ Ref operator[](const int k) { return Ref{p[k >> 1], k & 1}; }
+  __device__ __forceinline__ float operator[](const int k) const { return (k & 1) ? p[k >> 1].y : p[k >> 1].x; }
+};
+
 template <int N>
 struct SV {
-  float re[1 << N];
-  float im[1 << N];
+  qf2 a[1 << N];   // a[k] = (re, im) of amplitude k
 };
 
 // insert a zero bit at position B into k
@@ -25,52 +68,47 @@ __host__ __device__ constexpr int qc_popc(int k) { return k == 0 ? 0 : (k & 1) +
 // ------------------------------------------------------------------ single-bit gates
 // `s` carries the sign: the adjoint of a rotation is the same body with s -> -s.
 template <int N, int B>
-__device__ __forceinline__ void g_rx(SV<N>& v, float c, float s) {
+__device__ __forceinline__ void g_rx(SV<N>& v, float c, float s) {   // [[c, -i s], [-i s, c]]
+  const qf2 cv = qc_dup(c), sv = qc_pm(s);
 #pragma unroll
   for (int k = 0; k < (1 << (N - 1)); ++k) {
     const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
-    const float ar = v.re[i0], ai = v.im[i0], br = v.re[i1], bi = v.im[i1];
-    v.re[i0] = fmaf(s, bi, c * ar);
-    v.im[i0] = fmaf(-s, br, c * ai);
-    v.re[i1] = fmaf(s, ai, c * br);
-    v.im[i1] = fmaf(-s, ar, c * bi);
+    const qf2 a = v.a[i0], b = v.a[i1];
+    v.a[i0] = qc_pk_fma(sv, qc_swp(b), cv * a);   // c a - i s b = c a + s (b.im, -b.re)
+    v.a[i1] = qc_pk_fma(sv, qc_swp(a), cv * b);
   }
 }
 template <int N, int B>
-__device__ __forceinline__ void g_ry(SV<N>& v, float c, float s) {
+__device__ __forceinline__ void g_ry(SV<N>& v, float c, float s) {   // [[c, -s], [s, c]]
+  const qf2 cv = qc_dup(c), sv = qc_dup(s);
 #pragma unroll
   for (int k = 0; k < (1 << (N - 1)); ++k) {
     const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
-    const float ar = v.re[i0], ai = v.im[i0], br = v.re[i1], bi = v.im[i1];
-    v.re[i0] = fmaf(-s, br, c * ar);
-    v.im[i0] = fmaf(-s, bi, c * ai);
-    v.re[i1] = fmaf(s, ar, c * br);
-    v.im[i1] = fmaf(s, ai, c * bi);
+    const qf2 a = v.a[i0], b = v.a[i1];
+    v.a[i0] = qc_pk_fma(-sv, b, cv * a);
+    v.a[i1] = qc_pk_fma(sv, a, cv * b);
   }
 }
 template <int N, int B>
-__device__ __forceinline__ void g_rz(SV<N>& v, float c, float s) {
+__device__ __forceinline__ void g_rz(SV<N>& v, float c, float s) {   // diag(c - i s, c + i s)
+  const qf2 cv = qc_dup(c), sv = qc_pm(s);
 #pragma unroll
   for (int k = 0; k < (1 << (N - 1)); ++k) {
     const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
-    const float ar = v.re[i0], ai = v.im[i0], br = v.re[i1], bi = v.im[i1];
-    v.re[i0] = fmaf(s, ai, c * ar);   // * (c - i s)
-    v.im[i0] = fmaf(-s, ar, c * ai);
-    v.re[i1] = fmaf(-s, bi, c * br);  // * (c + i s)
-    v.im[i1] = fmaf(s, br, c * bi);
+    const qf2 a = v.a[i0], b = v.a[i1];
+    v.a[i0] = qc_pk_fma(sv, qc_swp(a), cv * a);
+    v.a[i1] = qc_pk_fma(-sv, qc_swp(b), cv * b);
   }
 }
 template <int N, int B>
 __device__ __forceinline__ void g_h(SV<N>& v) {
-  const float r = 0.70710678118654752440f;
+  const qf2 r = qc_dup(0.70710678118654752440f);
 #pragma unroll
   for (int k = 0; k < (1 << (N - 1)); ++k) {
     const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
-    const float ar = v.re[i0], ai = v.im[i0], br = v.re[i1], bi = v.im[i1];
-    v.re[i0] = (ar + br) * r;
-    v.im[i0] = (ai + bi) * r;
-    v.re[i1] = (ar - br) * r;
-    v.im[i1] = (ai - bi) * r;
+    const qf2 a = v.a[i0], b = v.a[i1];
+    v.a[i0] = (a + b) * r;
+    v.a[i1] = (a - b) * r;
   }
 }
 
@@ -84,126 +122,124 @@ __device__ __forceinline__ void g_cnot(SV<N>& v) {
 #pragma unroll
   for (int k = 0; k < (1 << (N - 2)); ++k) {
     const int i0 = qc_ctl_base<CB, TB>(k) | (1 << CB), i1 = i0 | (1 << TB);
-    const float ar = v.re[i0], ai = v.im[i0];
-    v.re[i0] = v.re[i1];
-    v.im[i0] = v.im[i1];
-    v.re[i1] = ar;
-    v.im[i1] = ai;
+    const qf2 a = v.a[i0];
+    v.a[i0] = v.a[i1];
+    v.a[i1] = a;
   }
 }
 template <int N, int CB, int TB>
 __device__ __forceinline__ void g_crx(SV<N>& v, float c, float s) {
+  const qf2 cv = qc_dup(c), sv = qc_pm(s);
 #pragma unroll
   for (int k = 0; k < (1 << (N - 2)); ++k) {
     const int i0 = qc_ctl_base<CB, TB>(k) | (1 << CB), i1 = i0 | (1 << TB);
-    const float ar = v.re[i0], ai = v.im[i0], br = v.re[i1], bi = v.im[i1];
-    v.re[i0] = fmaf(s, bi, c * ar);
-    v.im[i0] = fmaf(-s, br, c * ai);
-    v.re[i1] = fmaf(s, ai, c * br);
-    v.im[i1] = fmaf(-s, ar, c * bi);
+    const qf2 a = v.a[i0], b = v.a[i1];
+    v.a[i0] = qc_pk_fma(sv, qc_swp(b), cv * a);
+    v.a[i1] = qc_pk_fma(sv, qc_swp(a), cv * b);
   }
 }
 template <int N, int CB, int TB>
 __device__ __forceinline__ void g_crz(SV<N>& v, float c, float s) {
+  const qf2 cv = qc_dup(c), sv = qc_pm(s);
 #pragma unroll
   for (int k = 0; k < (1 << (N - 2)); ++k) {
     const int i0 = qc_ctl_base<CB, TB>(k) | (1 << CB), i1 = i0 | (1 << TB);
-    const float ar = v.re[i0], ai = v.im[i0], br = v.re[i1], bi = v.im[i1];
-    v.re[i0] = fmaf(s, ai, c * ar);
-    v.im[i0] = fmaf(-s, ar, c * ai);
-    v.re[i1] = fmaf(-s, bi, c * br);
-    v.im[i1] = fmaf(s, br, c * bi);
+    const qf2 a = v.a[i0], b = v.a[i1];
+    v.a[i0] = qc_pk_fma(sv, qc_swp(a), cv * a);
+    v.a[i1] = qc_pk_fma(-sv, qc_swp(b), cv * b);
   }
 }
 
 // ------------------------------------------------------------------ fixed two-wire unitary
-// `u` points at 32 floats: row-major 4x4, (re, im) interleaved; wave-uniform address.
-template <int N, int HB, int LB>
-__device__ __forceinline__ void g_u4(SV<N>& v, const float* __restrict__ u) {
+// `u` points at 32 floats: row-major 4x4, (re, im) interleaved; wave-uniform address.  The four output rows are
+// accumulated side by side (consecutive packed instructions never depend on each other).
+template <int N, int HB, int LB, class UP = const float* __restrict__>
+__device__ __forceinline__ void g_u4(SV<N>& v, UP u) {
 #pragma unroll
   for (int k = 0; k < (1 << (N - 2)); ++k) {
     const int b = qc_ctl_base<HB, LB>(k);
     const int idx[4] = {b, b | (1 << LB), b | (1 << HB), b | (1 << HB) | (1 << LB)};
-    float xr[4], xi[4];
+    qf2 x[4], y[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xr[j] = v.re[idx[j]];
-      xi[j] = v.im[idx[j]];
+    for (int j = 0; j < 4; ++j) x[j] = v.a[idx[j]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = qc_dup(u[(r * 4) * 2]) * x[0];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = qc_pk_fma(qc_mp(u[(r * 4) * 2 + 1]), qc_swp(x[0]), y[r]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = qc_pk_fma(qc_dup(u[(r * 4 + j) * 2]), x[j], y[r]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] = qc_pk_fma(qc_mp(u[(r * 4 + j) * 2 + 1]), qc_swp(x[j]), y[r]);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float yr = 0.f, yi = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float ur = u[(r * 4 + j) * 2], ui = u[(r * 4 + j) * 2 + 1];
-        yr = fmaf(ur, xr[j], yr);
-        yr = fmaf(-ui, xi[j], yr);
-        yi = fmaf(ur, xi[j], yi);
-        yi = fmaf(ui, xr[j], yi);
-      }
-      v.re[idx[r]] = yr;
-      v.im[idx[r]] = yi;
-    }
+    for (int r = 0; r < 4; ++r) v.a[idx[r]] = y[r];
   }
 }
 
 // ------------------------------------------------------------------ generator inner products
 // Im <lam| G |chi> for the gate generators: what the adjoint sweep accumulates per parameter.
+// Im(conj(l) y) = l.re y.im - l.im y.re = (lo - hi) of l * swap(y); sums run on pairs, one subtraction at the end.
 template <int N, int B>
 __device__ __forceinline__ float ip_x(const SV<N>& l, const SV<N>& x) {
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < (1 << N); ++k) {
-    const int j = k ^ (1 << B);
-    acc = fmaf(l.re[k], x.im[j], acc);
-    acc = fmaf(-l.im[k], x.re[j], acc);
-  }
-  return acc;
-}
-template <int N, int B>
-__device__ __forceinline__ float ip_z(const SV<N>& l, const SV<N>& x) {
-  float acc = 0.f;
-#pragma unroll
-  for (int k = 0; k < (1 << N); ++k) {
-    const float t = l.re[k] * x.im[k] - l.im[k] * x.re[k];
-    acc += ((k >> B) & 1) ? -t : t;
-  }
-  return acc;
-}
-template <int N, int B>
-__device__ __forceinline__ float ip_y(const SV<N>& l, const SV<N>& x) {
-  float acc = 0.f;
+  qf2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < (1 << (N - 1)); ++k) {
     const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
-    acc -= l.re[i0] * x.re[i1] + l.im[i0] * x.im[i1];
-    acc += l.re[i1] * x.re[i0] + l.im[i1] * x.im[i0];
+    acc0 = qc_pk_fma(l.a[i0], qc_swp(x.a[i1]), acc0);
+    acc1 = qc_pk_fma(l.a[i1], qc_swp(x.a[i0]), acc1);
   }
-  return acc;
+  const qf2 acc = acc0 + acc1;
+  return acc.x - acc.y;
+}
+template <int N, int B>
+__device__ __forceinline__ float ip_z(const SV<N>& l, const SV<N>& x) {
+  qf2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < (1 << (N - 1)); ++k) {
+    const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
+    acc0 = qc_pk_fma(l.a[i0], qc_swp(x.a[i0]), acc0);
+    acc1 = qc_pk_fma(l.a[i1], qc_swp(x.a[i1]), acc1);
+  }
+  const qf2 acc = acc0 - acc1;
+  return acc.x - acc.y;
+}
+template <int N, int B>
+__device__ __forceinline__ float ip_y(const SV<N>& l, const SV<N>& x) {   // Re(conj(l_1) x_0 - conj(l_0) x_1)
+  qf2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < (1 << (N - 1)); ++k) {
+    const int i0 = qc_ins0(k, B), i1 = i0 | (1 << B);
+    acc0 = qc_pk_fma(l.a[i1], x.a[i0], acc0);
+    acc1 = qc_pk_fma(l.a[i0], x.a[i1], acc1);
+  }
+  const qf2 acc = acc0 - acc1;
+  return acc.x + acc.y;
 }
 template <int N, int CB, int TB>
 __device__ __forceinline__ float ip_cx(const SV<N>& l, const SV<N>& x) {
-  float acc = 0.f;
+  qf2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < (1 << (N - 2)); ++k) {
     const int i0 = qc_ctl_base<CB, TB>(k) | (1 << CB), i1 = i0 | (1 << TB);
-    acc = fmaf(l.re[i0], x.im[i1], acc);
-    acc = fmaf(-l.im[i0], x.re[i1], acc);
-    acc = fmaf(l.re[i1], x.im[i0], acc);
-    acc = fmaf(-l.im[i1], x.re[i0], acc);
+    acc0 = qc_pk_fma(l.a[i0], qc_swp(x.a[i1]), acc0);
+    acc1 = qc_pk_fma(l.a[i1], qc_swp(x.a[i0]), acc1);
   }
-  return acc;
+  const qf2 acc = acc0 + acc1;
+  return acc.x - acc.y;
 }
 template <int N, int CB, int TB>
 __device__ __forceinline__ float ip_cz(const SV<N>& l, const SV<N>& x) {
-  float acc = 0.f;
+  qf2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < (1 << (N - 2)); ++k) {
     const int i0 = qc_ctl_base<CB, TB>(k) | (1 << CB), i1 = i0 | (1 << TB);
-    acc += l.re[i0] * x.im[i0] - l.im[i0] * x.re[i0];
-    acc -= l.re[i1] * x.im[i1] - l.im[i1] * x.re[i1];
+    acc0 = qc_pk_fma(l.a[i0], qc_swp(x.a[i0]), acc0);
+    acc1 = qc_pk_fma(l.a[i1], qc_swp(x.a[i1]), acc1);
   }
-  return acc;
+  const qf2 acc = acc0 - acc1;
+  return acc.x - acc.y;
 }
 
 // ------------------------------------------------------------------ run-time dispatch
@@ -333,30 +369,45 @@ __device__ __forceinline__ float qc_gate_grad(const SV<N>& lam, const SV<N>& chi
 //   W0=[c,s], W1=(da/2)[-s,c], W2=(dda/2)[-s,c]-(da^2/4)[c,s];
 // the product series (P0,P1,P2) gives phi, d phi, d2 phi.  ORDER = highest series needed.
 template <int N, int ORDER>
-__device__ __forceinline__ void qc_embed_series(float (&P0)[1 << N], float (&P1)[1 << N], float (&P2)[1 << N],
+__device__ __forceinline__ void qc_embed_series(QcPk<(1 << N)>& P0, QcPk<(1 << N)>& P1, QcPk<(1 << N)>& P2,
                                                 const float (&ca)[N], const float (&sa)[N],
                                                 const float (&da)[N], const float (&dda)[N]) {
-  P0[0] = 1.f;
-  P1[0] = 0.f;
-  P2[0] = 0.f;
+  // level w holds 2^(w+1) magnitudes as 2^w pairs; the next wire turns every HALF h of pair i into pair 2i + h
+  // (one packed multiply by {c, s} with the half broadcast), wire 0 ends up the most significant index bit
+  {
+    const float c = ca[0], s = sa[0];
+    P0.p[0] = (qf2){c, s};
+    if constexpr (ORDER >= 1) P1.p[0] = (qf2){-0.5f * da[0] * s, 0.5f * da[0] * c};
+    if constexpr (ORDER >= 2) {
+      const float q = 0.25f * da[0] * da[0];
+      P2.p[0] = (qf2){-0.5f * dda[0] * s - q * c, 0.5f * dda[0] * c - q * s};
+    }
+  }
 #pragma unroll
-  for (int w = 0; w < N; ++w) {  // wire w becomes the next-lower index bit: wire 0 ends up MSB
+  for (int w = 1; w < N; ++w) {
     const float c = ca[w], s = sa[w];
-    const float w1_0 = -0.5f * da[w] * s, w1_1 = 0.5f * da[w] * c;
+    const qf2 cs = {c, s};
+    const qf2 w1 = {-0.5f * da[w] * s, 0.5f * da[w] * c};
     const float q = 0.25f * da[w] * da[w];
-    const float w2_0 = -0.5f * dda[w] * s - q * c, w2_1 = 0.5f * dda[w] * c - q * s;
+    const qf2 w2 = {-0.5f * dda[w] * s - q * c, 0.5f * dda[w] * c - q * s};
 #pragma unroll
-    for (int i = (1 << w) - 1; i >= 0; --i) {
-      const float p0 = P0[i], p1 = P1[i], p2 = P2[i];
-      P0[2 * i] = p0 * c;
-      P0[2 * i + 1] = p0 * s;
-      if constexpr (ORDER >= 1) {
-        P1[2 * i] = fmaf(p0, w1_0, p1 * c);
-        P1[2 * i + 1] = fmaf(p0, w1_1, p1 * s);
-      }
-      if constexpr (ORDER >= 2) {
-        P2[2 * i] = fmaf(p0, w2_0, fmaf(2.f * p1, w1_0, p2 * c));
-        P2[2 * i + 1] = fmaf(p0, w2_1, fmaf(2.f * p1, w1_1, p2 * s));
+    for (int i = (1 << (w - 1)) - 1; i >= 0; --i) {
+      const qf2 p0 = P0.p[i];
+      qf2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+      if constexpr (ORDER >= 1) p1 = P1.p[i];
+      if constexpr (ORDER >= 2) p2 = P2.p[i];
+#pragma unroll
+      for (int h = 1; h >= 0; --h) {
+        const qf2 b0 = qc_dup(h ? p0.y : p0.x);
+        P0.p[2 * i + h] = b0 * cs;
+        if constexpr (ORDER >= 1) {
+          const qf2 b1 = qc_dup(h ? p1.y : p1.x);
+          P1.p[2 * i + h] = qc_pk_fma(b0, w1, b1 * cs);
+          if constexpr (ORDER >= 2) {
+            const qf2 b2 = qc_dup(h ? p2.y : p2.x);
+            P2.p[2 * i + h] = qc_pk_fma(b0, w2, qc_pk_fma(b1 + b1, w1, b2 * cs));
+          }
+        }
       }
     }
   }
@@ -364,30 +415,26 @@ __device__ __forceinline__ void qc_embed_series(float (&P0)[1 << N], float (&P1)
 
 // real magnitudes -> complex amplitudes with the (-i)^{popcount} phase
 template <int N>
-__device__ __forceinline__ void qc_phase_load(SV<N>& v, const float (&P)[1 << N]) {
+__device__ __forceinline__ void qc_phase_load(SV<N>& v, const QcPk<(1 << N)>& P) {
 #pragma unroll
   for (int k = 0; k < (1 << N); ++k) {
     const int ph = qc_popc(k) & 3;
-    v.re[k] = (ph == 0) ? P[k] : (ph == 2 ? -P[k] : 0.f);
-    v.im[k] = (ph == 1) ? -P[k] : (ph == 3 ? P[k] : 0.f);
+    const qf2 m = ph == 0 ? (qf2){1.f, 0.f} : ph == 1 ? (qf2){0.f, -1.f} : ph == 2 ? (qf2){-1.f, 0.f} : (qf2){0.f, 1.f};
+    v.a[k] = qc_dup(P[k]) * m;
   }
 }
 
 // T[w] = Im <lam| X_w |phi>,  phi given by real magnitudes P (phase applied on the fly).
 template <int N>
-__device__ __forceinline__ void qc_embed_ip(float (&T)[N], const SV<N>& lam, const float (&P)[1 << N]) {
+__device__ __forceinline__ void qc_embed_ip(float (&T)[N], const SV<N>& lam, const QcPk<(1 << N)>& P) {
   SV<N> phi;
   qc_phase_load<N>(phi, P);
 #pragma unroll
   for (int w = 0; w < N; ++w) {
-    float acc = 0.f;
+    qf2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < (1 << N); ++k) {
-      const int j = k ^ (1 << (N - 1 - w));
-      acc = fmaf(lam.re[k], phi.im[j], acc);
-      acc = fmaf(-lam.im[k], phi.re[j], acc);
-    }
-    T[w] = acc;
+    for (int k = 0; k < (1 << N); ++k) acc = qc_pk_fma(lam.a[k], qc_swp(phi.a[k ^ (1 << (N - 1 - w))]), acc);
+    T[w] = acc.x - acc.y;
   }
 }
 
@@ -408,7 +455,7 @@ __device__ __forceinline__ void qc_unembed(SV<N>& v, const float (&ca)[N], const
 template <int N>
 __device__ __forceinline__ void qc_pull_ip0(float (&T)[N], const SV<N>& mu) {
 #pragma unroll
-  for (int w = 0; w < N; ++w) T[w] = -mu.im[1 << (N - 1 - w)];
+  for (int w = 0; w < N; ++w) T[w] = -mu.a[1 << (N - 1 - w)].y;
 }
 // T[w] = Im <mu| X_w |kappa_s>
 template <int N>
@@ -416,10 +463,10 @@ __device__ __forceinline__ void qc_pull_ip1(float (&T)[N], const SV<N>& mu, cons
 #pragma unroll
   for (int w = 0; w < N; ++w) {
     const int bw = 1 << (N - 1 - w);
-    float acc = da[w] * mu.re[0];
+    float acc = da[w] * mu.a[0].x;
 #pragma unroll
     for (int v = 0; v < N; ++v)
-      if (v != w) acc = fmaf(da[v], mu.re[bw | (1 << (N - 1 - v))], acc);
+      if (v != w) acc = fmaf(da[v], mu.a[bw | (1 << (N - 1 - v))].x, acc);
     T[w] = -0.5f * acc;
   }
 }
@@ -433,14 +480,14 @@ __device__ __forceinline__ void qc_pull_ip2(float (&T)[N], const SV<N>& mu, cons
 #pragma unroll
   for (int w = 0; w < N; ++w) {
     const int bw = 1 << (N - 1 - w);
-    float a = S * mu.im[bw];
-    float b = dda[w] * mu.re[0];
+    float a = S * mu.a[bw].y;
+    float b = dda[w] * mu.a[0].x;
 #pragma unroll
     for (int u = 0; u < N; ++u) {
-      if (u != w) b = fmaf(dda[u], mu.re[bw | (1 << (N - 1 - u))], b);
+      if (u != w) b = fmaf(dda[u], mu.a[bw | (1 << (N - 1 - u))].x, b);
 #pragma unroll
       for (int v = u + 1; v < N; ++v)
-        a = fmaf(2.f * da[u] * da[v], mu.im[(1 << (N - 1 - u)) ^ (1 << (N - 1 - v)) ^ bw], a);
+        a = fmaf(2.f * da[u] * da[v], mu.a[(1 << (N - 1 - u)) ^ (1 << (N - 1 - v)) ^ bw].y, a);
     }
     T[w] = 0.25f * a - 0.5f * b;
   }
@@ -448,12 +495,31 @@ __device__ __forceinline__ void qc_pull_ip2(float (&T)[N], const SV<N>& mu, cons
 
 // <Z_w> style signed sums: out[w] = sum_k t[k] * (1 - 2 bit_{N-1-w}(k))
 template <int N>
-__device__ __forceinline__ void qc_signed_sums(float (&out)[N], const float (&t)[1 << N]) {
+__device__ __forceinline__ void qc_signed_sums(float (&out)[N], const QcPk<(1 << N)>& t) {
 #pragma unroll
   for (int w = 0; w < N; ++w) {
-    float acc = 0.f;
+    const int b = N - 1 - w;   // index bit of wire w; bit 0 = the two halves of a pair
+    qf2 acc = {0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < (1 << N); ++k) acc += ((k >> (N - 1 - w)) & 1) ? -t[k] : t[k];
-    out[w] = acc;
+    for (int j = 0; j < (1 << (N - 1)); ++j) {
+      if (b >= 1 && ((j >> (b >= 1 ? b - 1 : 0)) & 1)) acc -= t.p[j];
+      else acc += t.p[j];
+    }
+    out[w] = b == 0 ? acc.x - acc.y : acc.x + acc.y;
+  }
+}
+
+// d[k] = sum_w q[w] (1 - 2 bit_{N-1-w}(k)): the diagonal of sum_w q_w Z_w, built by doubling (pair-index bit m = wire N-2-m)
+template <int N>
+__device__ __forceinline__ void qc_sign_sums(QcPk<(1 << N)>& d, const float (&q)[N]) {
+  d.p[0] = (qf2){q[N - 1], -q[N - 1]};
+#pragma unroll
+  for (int m = 0; m < N - 1; ++m) {
+    const qf2 qw = qc_dup(q[N - 2 - m]);
+#pragma unroll
+    for (int j = 0; j < (1 << m); ++j) {
+      d.p[j | (1 << m)] = d.p[j] - qw;
+      d.p[j] = d.p[j] + qw;
+    }
   }
 }
