@@ -134,3 +134,45 @@ def test_full_size_determinism_and_additivity(over, B, tol, gpu_device):
     scale = max(1.0, f1.abs().max().item())
     assert (rfull + full_val - f1).abs().max().item() < tol * scale
     assert f1[NP:].min().item() >= 0.0
+
+
+@pytest.mark.parametrize("over,B", [
+    ({"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"}, 131),    # 2 tiles + 3 points: a pass group
+    ({"num_qubits": 7, "num_quantum_layers": 1, "q_ansatz": "layered"}, 70),     # of four with dead points
+    ({"num_qubits": 6, "num_quantum_layers": 1, "q_ansatz": "cascade"}, 65),
+])
+def test_wave_family_ragged_batches_kept_equals_recompute(over, B, gpu_device):
+    """n = 6..8 compile-time programs run four points side by side in a wave; a residual batch that is not a multiple
+    of four leaves dead points in the last pass group (zero cotangents, no stores).  The kept-state path
+    (k_wave_jets_fwd1 / k_wave_jets_bwd1, four points per wave) must give the gradient of the recompute path
+    (six-wave kernels with their own tail handling), and both the gradient of the same points fed one tile at a time."""
+    L = pkg("hip.lib")
+    engine = pkg("hip.engine")
+    X_ic, X_bc, X_res = _batches(B, 21)
+    model = make(gpu_device, **over)
+    dev = model._flat.device
+    eng = model._engine_for(dev)
+    eng.refresh_gates()
+    opt = engine.OptimState(eng.NP, 0.005, dev)
+    fs = engine.FusedStep(eng, B, X_ic.shape[0], X_bc.shape[0], opt, (B, X_ic.shape[0], X_bc.shape[0]))
+    fs.X_res[:B] = X_res.to(dev)
+    fs.X_val[:X_ic.shape[0]] = X_ic.to(dev)
+    fs.X_val[X_ic.shape[0]:X_ic.shape[0] + X_bc.shape[0]] = X_bc.to(dev)
+    assert int(fs.desc.circ_ws_bytes) > 0, "this case must have a kept-state store"
+    fs.run(L.QC_PHASE_GRADS)
+    torch.cuda.synchronize()
+    kept = fs.flat_grad.clone()
+    fs.desc.circ_ws_dev, fs.desc.circ_ws_bytes = None, 0
+    fs.run(L.QC_PHASE_GRADS)
+    torch.cuda.synchronize()
+    recomputed = fs.flat_grad.clone()
+    assert torch.isfinite(kept).all()
+    scale = max(1.0, kept.abs().max().item())
+    assert (kept - recomputed).abs().max().item() <= 2e-7 * scale
+    # batch additivity across the ragged cut: means over [0, 64) and [64, B) recombine with their weights
+    none = X_ic[:0]
+    a = grads_for(model, none, none, X_res[:64])
+    b = grads_for(model, none, none, X_res[64:])
+    full = grads_for(model, none, none, X_res)
+    w = 64.0 / B
+    assert (w * a + (1.0 - w) * b - full).abs().max().item() < 5e-6 * max(1.0, full.abs().max().item())
