@@ -698,7 +698,7 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
                                                    const float* __restrict__ ajets, const float* __restrict__ qbar,
                                                    float* __restrict__ abar, float* __restrict__ part,
                                                    int64_t part_stride, int64_t row0, int64_t B,
-                                                   const float* __restrict__ chi_store, int amp) {
+                                                   const float* __restrict__ chi_store, int amp, int stagger = 0) {
   constexpr int N = PG::N;
   constexpr int A2 = 2 << N;
   constexpr int NA = 1 << N;
@@ -713,6 +713,12 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
   const bool live = p < B;
   const int64_t pc = live ? p : B - 1;
   for (int i = threadIdx.x; i < 3 * n_params; i += 192) s_acc[i] = 0.f;
+  // every second tile can start late (stagger x 8 128 cycles): the whole grid is resident in one round, so all waves
+  // load at the same time and then all sweep at the same time (HBM and VALU take turns instead of overlapping)
+  if (stagger > 0 && (bid & 1)) {
+#pragma unroll 1
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // wires wv, wv + 3, ... of the embedding half-angles
   for (int w = wv; w < N; w += 3) qc_wire_sincos(s_cs[w * 64 + lane], s_cs[(N + w) * 64 + lane], ajets, B, pc, w, trig, amp >> 1);
   // the point index as an opaque value: addresses derived from it are recomputed at their use instead of being hoisted
@@ -884,9 +890,11 @@ __global__ void __launch_bounds__(192, 4) k_circ_bwd_both2(
     const float* __restrict__ ajets, const float* __restrict__ qbar, float* __restrict__ abar, int64_t row0_r, int64_t Br,
     const float* __restrict__ chi_store, const float* __restrict__ angles, const float* __restrict__ cot,
     float* __restrict__ d_angles, int64_t row0_v, int64_t Bv, float* __restrict__ part, int64_t part_stride, int amp, int n_val) {
+  const int stagger = amp >> 8;   // (launcher: bits 8.. of the flags word)
+  amp &= 0xff;
   if ((int)blockIdx.x >= n_val)
     k_jets_bwd2_body<PG>(blockIdx.x - n_val, prog, trig, umat, n_gates, n_params, ajets, qbar, abar, part, part_stride, row0_r, Br,
-                         chi_store, amp);
+                         chi_store, amp, stagger);
   else
     k_value_bwd_body<PG, 3>(blockIdx.x, prog, trig, umat, n_gates, n_params, angles, cot, d_angles, part, part_stride,
                             row0_v, Bv, amp);
@@ -972,12 +980,13 @@ struct RegLaunch {
                            const float* angles, const float* cot, float* d_angles, int64_t row0_v, int64_t Bv, float* part,
                            int64_t part_stride, hipStream_t st) {
     static const bool six = [] { const char* e = getenv("QC_BWD6"); return e && e[0] == '1'; }();   // A/B: the six-wave form
+    static const int stagger = [] { const char* e = getenv("QC_BWD2_STAGGER"); return e ? atoi(e) & 0xff : 0; }();
     if (!six && !pg->amplitude) {
       const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 192);
       const size_t sh = ((size_t)3 * (2u << PG::N) * 64 + (size_t)4 * PG::N * 64 + (size_t)3 * pg->n_params) * sizeof(float);
       hipLaunchKernelGGL(k_circ_bwd_both2<PG>, dim3(nr + nv), dim3(192), sh, st, pg->d_gates, trig, umat, pg->n_gates,
                          pg->n_params, ajets, qbar, abar, row0_r, Br, chi_store, angles, cot, d_angles, row0_v, Bv, part,
-                         part_stride, qc_embed_flags(pg), nv);
+                         part_stride, qc_embed_flags(pg) | (stagger << 8), nv);
       return QC_OK;
     }
     const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 384);
