@@ -130,7 +130,10 @@ typedef struct qc_pde {
 /* mode 0: qjets -> u [B], residual [B] (nn/pde.py:71);
  * mode 1: cotangents (ubar, rbar) [B] -> qbar jets + weight-gradient partial rows;
  * mode 2: forward + analytic targets (data/diffusion_dataset.py:20-38) + squared error + reverse;
- *         out_u_dev / out_res_dev are then B-float scratch buffers (per-point cotangents). */
+ *         out_u_dev / out_res_dev are then B-float scratch buffers (per-point cotangents);
+ * mode 4 (nch = 6): qjets -> all six derivative channels of u, out_u_dev = [6][B] (value, d/dt, d/dx, d/dy, d2/dx2,
+ *         d2/dy2): operators that are not linear in the channels (Navier-Stokes, nn/pde.py:2-27) combine them outside;
+ * mode 3 (nch = 6): its reverse: in_ubar_dev = [6][B] cotangents of those channels -> qbar jets + partial rows. */
 int qc_post(int mode, const float* X_dev, const float* params_dev, int H, int n, int n_theta,
             const qc_pde* pde, const float* qjets_dev, float* out_u_dev, float* out_res_dev,
             const float* in_ubar_dev, const float* in_rbar_dev, float* qbar_dev, float* part_dev,

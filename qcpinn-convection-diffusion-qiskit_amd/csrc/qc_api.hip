@@ -422,9 +422,11 @@ int qc_post(int mode, const float* X, const float* prm, int H, int n, int n_thet
   int rc = check_mlp(H, n, n_theta, B, nch);
   if (rc) return rc;
   const QcLayout L = make_layout(H, n, n_theta);
-  if (mode < 0 || mode > 2 || !X || !prm || !pde || !qjets) return QC_ERR_ARG;
-  if (mode >= 1 && (!qbar || !part || row0 < 0 || part_stride < L.NP + (mode == 2 ? 3 : 0))) return QC_ERR_ARG;
+  if (mode < 0 || mode > 4 || !X || !prm || !pde || !qjets) return QC_ERR_ARG;
+  if (mode >= 3 && nch != 6) return QC_ERR_ARG;          // general jets: six channels only
+  if (mode >= 1 && mode <= 3 && (!qbar || !part || row0 < 0 || part_stride < L.NP + (mode == 2 ? 3 : 0))) return QC_ERR_ARG;
   if (mode == 2 && (!out_u || (nch == 6 && !out_res))) return QC_ERR_ARG;  // per-point cotangent scratch
+  if ((mode == 3 && !in_ubar) || (mode == 4 && !out_u)) return QC_ERR_ARG;
   rc = qc_mlp_post(mode, X, prm, L, to_pde(pde), qjets, out_u, out_res, in_ubar, in_rbar, qbar, part, part_stride,
                    row0, B, nch, (hipStream_t)stream);
   return rc ? rc : after_launch();

@@ -256,6 +256,9 @@ __global__ void k_pre_bwd(const float* __restrict__ X, const float* __restrict__
 // MODE 1: reverse only: cotangents (ubar, rbar) come from memory (autograd path) -> qbar
 // MODE 2: forward + analytic targets + squared error (loss sums into the tile's partial row)
 //         + reverse -> qbar; the per-point cotangents (ubar, rbar-scale) are left in ub_out[2][B]
+// MODE 3: reverse only, GENERAL cotangents: in_ubar = [6][B], one per derivative channel of u (operators that are not
+//         linear in the channels, e.g. Navier-Stokes' u u_x) -> qbar
+// MODE 4: forward only, all six channels of u -> out_u[6][B] (value, d/dt, d/dx, d/dy, d2/dx2, d2/dy2)
 // The weight gradients of W3/b3/W4/b4 are NOT formed here (they would need ~300 cross-lane
 // reductions per wave): k_post_wg below forms them with lane = hidden unit.
 template <int N, int NCH>
@@ -330,7 +333,7 @@ __device__ __forceinline__ void k_post_body(const int64_t bid, const float* __re
 #pragma unroll
       for (int i = 0; i < N; ++i) qbu[c][i] = 0.f;
   }
-  if constexpr (MODE == 0 || MODE == 2) {
+  if constexpr (MODE == 0 || MODE == 2 || MODE == 4) {
     float u[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) u[c] = 0.f;
@@ -375,6 +378,13 @@ __device__ __forceinline__ void k_post_body(const int64_t bid, const float* __re
       u[c] = (s_buf[0][c][lane] + s_buf[1][c][lane]) + (s_buf[2][c][lane] + s_buf[3][c][lane]);
     __syncthreads();   // s_buf is reused for the qbar partials below
     u[0] += prm[L.ob4];
+    if constexpr (MODE == 4) {
+      if (live && wave == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) out_u[(int64_t)c * B + p] = u[c];
+      }
+      return;
+    }
     float res = 0.f;
     if constexpr (NCH == 6) res = pde.c_t * u[1] + pde.c_x * u[2] + pde.c_y * u[3] - (pde.d_xx * u[4] + pde.d_yy * u[5]);
     if constexpr (MODE == 0) {
@@ -438,9 +448,14 @@ __device__ __forceinline__ void k_post_body(const int64_t bid, const float* __re
         qbar[(int64_t)f * B + p] = (s_buf[0][f][lane] + s_buf[1][f][lane]) + (s_buf[2][f][lane] + s_buf[3][f][lane]);
     }
   }
-  if constexpr (MODE == 1) {
+  if constexpr (MODE == 1 || MODE == 3) {
     float ub[NCH];
-    expand_ub<NCH>(ub, ub0, gsc, pde);
+    if constexpr (MODE == 3) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) ub[c] = live ? in_ubar[(int64_t)c * B + pc] : 0.f;
+    } else {
+      expand_ub<NCH>(ub, ub0, gsc, pde);
+    }
     float qb[NCH][N];
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
@@ -493,9 +508,10 @@ __global__ void __launch_bounds__(256) k_post(const float* __restrict__ X, const
 template <int N, int NCH>
 __device__ __forceinline__ void k_post_wg_body(const int64_t bid, const float* __restrict__ prm, QcLayout L, QcPde pde, const float* __restrict__ qjets,
                           const float* __restrict__ ubar, const float* __restrict__ rbar,
-                          float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B, int HB, int PS) {
+                          float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B, int HB, int PS,
+                          int gen = 0) {
   __shared__ float sQ[NCH * N][64];
-  __shared__ float sU[2][64];
+  __shared__ float sU[NCH == 6 ? 6 : 2][64];   // rows 0, 1: (ubar, rbar); gen: one row per derivative channel of u
   extern __shared__ float s_acc[];  // [PS][N + 2][HB]
   const int64_t base = (int64_t)bid * 64;
   const int cnt = (int)((B - base) < 64 ? (B - base) : 64);
@@ -503,10 +519,17 @@ __device__ __forceinline__ void k_post_wg_body(const int64_t bid, const float* _
     const int f = i >> 6, pp = i & 63;
     sQ[f][pp] = pp < cnt ? qjets[(int64_t)f * B + base + pp] : 0.f;
   }
-  for (int i = threadIdx.x; i < 128; i += blockDim.x) {
-    const int k = i >> 6, pp = i & 63;
-    const float* src = k == 0 ? ubar : rbar;
-    sU[k][pp] = (pp < cnt && src != nullptr) ? src[base + pp] : 0.f;
+  if (NCH == 6 && gen) {
+    for (int i = threadIdx.x; i < 6 * 64; i += blockDim.x) {
+      const int k = i >> 6, pp = i & 63;
+      sU[k][pp] = pp < cnt ? ubar[(int64_t)k * B + base + pp] : 0.f;
+    }
+  } else {
+    for (int i = threadIdx.x; i < 128; i += blockDim.x) {
+      const int k = i >> 6, pp = i & 63;
+      const float* src = k == 0 ? ubar : rbar;
+      sU[k][pp] = (pp < cnt && src != nullptr) ? src[base + pp] : 0.f;
+    }
   }
   __syncthreads();
   const int grp = threadIdx.x / HB, m = threadIdx.x % HB;   // threads past HB * PS (block rounded up to waves) idle
@@ -531,7 +554,12 @@ __device__ __forceinline__ void k_post_wg_body(const int64_t bid, const float* _
       }
       const float z = qc_tanh(g[0]);
       float ub[NCH];
-      expand_ub<NCH>(ub, sU[0][pp], sU[1][pp], pde);
+      if (NCH == 6 && gen) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) ub[c] = sU[c < (NCH == 6 ? 6 : 2) ? c : 0][pp];
+      } else {
+        expand_ub<NCH>(ub, sU[0][pp], sU[1][pp], pde);
+      }
       float gb[NCH], gw4;
       post_cotangents<N, NCH>(gb, gw4, g, ub, z, w4);
       gW4 += gw4;
@@ -577,8 +605,8 @@ __device__ __forceinline__ void k_post_wg_body(const int64_t bid, const float* _
 template <int N, int NCH>
 __global__ void k_post_wg(const float* __restrict__ prm, QcLayout L, QcPde pde, const float* __restrict__ qjets,
                           const float* __restrict__ ubar, const float* __restrict__ rbar,
-                          float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B, int HB, int PS) {
-  k_post_wg_body<N, NCH>(blockIdx.x, prm, L, pde, qjets, ubar, rbar, part, part_stride, row0, B, HB, PS);
+                          float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B, int HB, int PS, int gen) {
+  k_post_wg_body<N, NCH>(blockIdx.x, prm, L, pde, qjets, ubar, rbar, part, part_stride, row0, B, HB, PS, gen);
 }
 
 // ================================================================== value tiles, one wave per tile
@@ -815,18 +843,21 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
   hidden_geometry(L.H, &HB, &PS, &threads);
   const size_t sh = (size_t)PS * (L.n + 2) * HB * sizeof(float);
   // cotangent sources of the weight-gradient kernel: given (mode 1) or produced by the point kernel (mode 2)
-  const float* ub_src = mode == 1 ? in_ubar : out_u;
+  const float* ub_src = (mode == 1 || mode == 3) ? in_ubar : out_u;
   const float* rb_src = mode == 1 ? in_rbar : out_res;
+  const int gen = mode == 3 ? 1 : 0;
 #define LAUNCH(NN, CC, MM)                                                                              \
   hipLaunchKernelGGL((k_post<NN, CC, MM>), dim3(tiles), dim3(256), 0, st, X, prm, L, pde, qjets, out_u,  \
                      out_res, in_ubar, in_rbar, qbar, part, part_stride, row0, B)
 #define LAUNCH_WG(NN, CC)                                                                               \
   hipLaunchKernelGGL((k_post_wg<NN, CC>), dim3(tiles), dim3(threads), sh, st, prm, L, pde, qjets,        \
-                     ub_src, (CC == 6 ? rb_src : nullptr), part, part_stride, row0, B, HB, PS)
+                     ub_src, (CC == 6 ? rb_src : nullptr), part, part_stride, row0, B, HB, PS, gen)
 #define CALL(NN)                                                         \
   if (nch == 6) {                                                        \
     if (mode == 0) LAUNCH(NN, 6, 0);                                     \
     else if (mode == 1) { LAUNCH(NN, 6, 1); LAUNCH_WG(NN, 6); }          \
+    else if (mode == 3) { LAUNCH(NN, 6, 3); LAUNCH_WG(NN, 6); }          \
+    else if (mode == 4) LAUNCH(NN, 6, 4);                                \
     else { LAUNCH(NN, 6, 2); LAUNCH_WG(NN, 6); }                         \
   } else {                                                               \
     if (mode == 0) LAUNCH(NN, 1, 0);                                     \

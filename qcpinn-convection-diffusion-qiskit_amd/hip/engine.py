@@ -224,8 +224,9 @@ class SolverEngine:
         return X
 
     # ------------------------------------------------------------------ forward passes
-    def forward(self, X: torch.Tensor, nch: int, refresh: bool = True):
-        """Returns (u, residual_or_None, ajets, qjets).  nch = 1: value only; 6: with residual."""
+    def forward(self, X: torch.Tensor, nch: int, refresh: bool = True, ujets: bool = False):
+        """Returns (u, residual_or_None, ajets, qjets).  nch = 1: value only; 6: with residual.  ``ujets`` (nch = 6):
+        the first element is the [6, B] tensor of u's derivative channels instead."""
         X = self._X(X)
         B = X.shape[0]
         st = _stream(self.device)
@@ -238,17 +239,24 @@ class SolverEngine:
             qjets = self.circuit.forward_expval(ajets[0]).unsqueeze(0)
         else:
             qjets = self.circuit.forward_jets(ajets)
+        pde = self._pde()
+        if ujets:      # all six derivative channels of u (qc_post mode 4) instead of (u, residual)
+            uj = torch.empty(NCH, B, dtype=torch.float32, device=self.device)
+            L.check(self.lib.qc_post(4, X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
+                                     C.byref(pde), qjets.data_ptr(), uj.data_ptr(), None, None, None, None, None,
+                                     0, 0, B, nch, st), "qc_post(forward, six channels)")
+            return uj, None, ajets, qjets
         u = torch.empty(B, 1, dtype=torch.float32, device=self.device)
         res = torch.empty(B, 1, dtype=torch.float32, device=self.device) if nch == NCH else None
-        pde = self._pde()
         L.check(self.lib.qc_post(0, X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
                                  C.byref(pde), qjets.data_ptr(), u.data_ptr(), _ptr(res), None, None, None, None,
                                  0, 0, B, nch, st), "qc_post(forward)")
         return u, res, ajets, qjets
 
     # ------------------------------------------------------------------ reverse pass (autograd path)
-    def backward(self, X, ajets, qjets, ubar, rbar, nch: int) -> torch.Tensor:
-        """Vector-Jacobian product of (u, residual) w.r.t. the flat parameters: returns d_flat (NP)."""
+    def backward(self, X, ajets, qjets, ubar, rbar, nch: int, ujets: bool = False) -> torch.Tensor:
+        """Vector-Jacobian product of (u, residual) w.r.t. the flat parameters: returns d_flat (NP).  ``ujets``:
+        ``ubar`` is the [6, B] cotangent of u's six derivative channels (qc_post mode 3), ``rbar`` unused."""
         X = self._X(X)
         B = X.shape[0]
         st = _stream(self.device)
@@ -257,8 +265,10 @@ class SolverEngine:
         qbar = torch.empty_like(qjets)
         pde = self._pde()
         ub = None if ubar is None else _need(ubar.reshape(-1), self.device, "ubar")
-        rb = None if rbar is None else _need(rbar.reshape(-1), self.device, "rbar")
-        L.check(self.lib.qc_post(1, X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
+        rb = None if (rbar is None or ujets) else _need(rbar.reshape(-1), self.device, "rbar")
+        if ujets and (ub is None or ub.numel() != NCH * B or nch != NCH):
+            raise L.QcError("the six-channel cotangent must be a [6, B] tensor")
+        L.check(self.lib.qc_post(3 if ujets else 1, X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
                                  C.byref(pde), qjets.data_ptr(), None, None, _ptr(ub), _ptr(rb), qbar.data_ptr(),
                                  part.data_ptr(), self.NP, 0, B, nch, st), "qc_post(backward)")
         abar = torch.empty_like(ajets)

@@ -69,6 +69,34 @@ class _ResidualFn(torch.autograd.Function):
         return (None, None, None) + ctx.solver._split_flat(d_flat)
 
 
+class _JetsFn(torch.autograd.Function):
+    """X (B,3) and ONE flat single-output parameter vector (kernel layout) -> the six derivative channels of that
+    output, (B,6) = (u, u_t, u_x, u_y, u_xx, u_yy); the reverse pass takes a cotangent per channel (qc_post modes 4 / 3).
+    The flat vector is assembled from the module's parameters by torch ops, so autograd carries its gradient on to
+    them: a K-output model is K single-output evaluations that share everything but one row of the last layer."""
+
+    @staticmethod
+    def forward(ctx, X, solver, flat):
+        eng = solver._jet_engine(X.device)
+        Xc = solver._pad_inputs(X.detach().to(torch.float32)).contiguous()
+        fl = flat.detach().to(torch.float32).contiguous()
+        eng.flat.copy_(fl)
+        uj, _, ajets, qjets = eng.forward(Xc, _engine.NCH, ujets=True)
+        ctx.eng = eng
+        ctx.save_for_backward(Xc, ajets, qjets, fl)
+        return uj.t().contiguous()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        Xc, ajets, qjets, fl = ctx.saved_tensors
+        eng = ctx.eng
+        eng.flat.copy_(fl)              # (another output's evaluation may have used the engine in between)
+        eng.refresh_gates()
+        d_flat = eng.backward(Xc, ajets, qjets, g.to(torch.float32).t().contiguous(), None, _engine.NCH, ujets=True)
+        return None, None, d_flat
+
+
 class DVPDESolver(nn.Module):
     def __init__(self, args, logger, data=None, device=None):
         super().__init__()
@@ -87,10 +115,13 @@ class DVPDESolver(nn.Module):
         self.classic_network = self.args["classic_network"]
         self.total_training_time = 0
         self.total_memory_peak = 0
-        if self.classic_network[0] not in (2, 3) or self.classic_network[-1] != 1:
+        if self.classic_network[0] not in (2, 3) or self.classic_network[-1] < 1:
             raise ValueError("the DV path maps (t, x, y) -> u (or two coordinates -> u for the second-order operators of "
-                             f"nn/pde.py): classic_network must be [3, H, 1] or [2, H, 1], got {self.classic_network}")
+                             f"nn/pde.py): classic_network must be [3, H, K] or [2, H, K], got {self.classic_network}")
         self.input_dim = self.classic_network[0]
+        # K > 1 outputs (Navier-Stokes' (u, v, p), nn/pde.py:2-27): served through jets(), one single-output
+        # evaluation of the kernels per output; the fused TRAINING step and residual() are for K = 1
+        self.n_out = self.classic_network[-1]
         hidden = self.classic_network[-2]
 
         # same construction order as the reference => same RNG consumption (nn/DVPDESolver.py:28-57)
@@ -114,10 +145,14 @@ class DVPDESolver(nn.Module):
         self._flat = None
         self._engines = {}
         self._fused_opt = None
+        self._jet_engines = {}
         target = self._resolve_device(device)
         if target is not None:
             self.device = target         # samplers of reference-style loops read model.device
-            self._pack(target)
+            if self.n_out == 1:
+                self._pack(target)
+            else:
+                self.to(target)
 
     # ------------------------------------------------------------------ device / flat storage
     @staticmethod
@@ -184,7 +219,49 @@ class DVPDESolver(nn.Module):
             return torch.cat([torch.zeros_like(X[:, :1]), X], dim=1)
         return X
 
+    def _jet_engine(self, device) -> "_engine.SolverEngine":
+        """Engine over a scratch flat vector in the single-output kernel layout (see _JetsFn)."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise QcError(f"DVPDESolver computes on the GPU only (HIP kernels, no CPU fallback); input is on {device}")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        key = device.index
+        if key not in self._jet_engines:
+            circ = self.quantum_layer._circuit_for(device)
+            H, n = self.hidden_width, self.num_qubits
+            NP = 3 * H + H + n * H + n + H * n + H + H + 1 + circ.n_params
+            self._jet_engines[key] = _engine.SolverEngine(circ, H, torch.zeros(NP, dtype=torch.float32, device=device))
+        return self._jet_engines[key]
+
+    def _flat_for_output(self, out: int) -> torch.Tensor:
+        """The parameters of output ``out`` as one flat vector in the kernels' single-output layout
+        (W1[H][3] b1 W2 b2 | W3 b3 W4[out] b4[out] | theta), built by differentiable torch ops."""
+        pre0, pre2 = self.preprocessor[0], self.preprocessor[2]
+        post0, post2 = self.postprocessor[0], self.postprocessor[2]
+        W1 = pre0.weight
+        if self.input_dim == 2:
+            W1 = torch.cat([torch.zeros_like(W1[:, :1]), W1], dim=1)
+        parts = [W1.reshape(-1), pre0.bias, pre2.weight.reshape(-1), pre2.bias, post0.weight.reshape(-1), post0.bias,
+                 post2.weight[out], post2.bias[out:out + 1]]
+        parts += [p.reshape(-1) for p in self.quantum_layer.parameters()]
+        return torch.cat([p.to(torch.float32) for p in parts])
+
+    def jets(self, X: torch.Tensor, out: int = 0) -> torch.Tensor:
+        """(B, 6) = (u, u_t, u_x, u_y, u_xx, u_yy) of output ``out`` at X (B, input_dim), from the fused derivative-channel
+        kernels; differentiable w.r.t. the parameters.  For operators that are not linear in the channels
+        (``nn.pde.navier_stokes_2D_operator``) and for K-output models."""
+        if X.dim() != 2 or X.shape[1] != self.input_dim:
+            raise ValueError(f"Expected points of shape (B, {self.input_dim}), got {tuple(X.shape)}")
+        if not 0 <= out < self.n_out:
+            raise ValueError(f"output index {out} outside [0, {self.n_out})")
+        self._jet_engine(X.device)
+        return _JetsFn.apply(X, self, self._flat_for_output(out))
+
     def _engine_for(self, device) -> "_engine.SolverEngine":
+        if self.n_out != 1:
+            raise NotImplementedError("residual() and the fused training step serve single-output models; a "
+                                      f"{self.n_out}-output model is evaluated through jets(X, out)")
         device = torch.device(device)
         if device.type != "cuda":
             raise QcError(f"DVPDESolver computes on the GPU only (HIP kernels, no CPU fallback); input is on {device}")
@@ -213,6 +290,10 @@ class DVPDESolver(nn.Module):
             if self.draw_quantum_circuit_flag:
                 self.draw_quantum_circuit(x)
                 self.draw_quantum_circuit_flag = False
+            if self.n_out != 1:       # (B, K): the value channel of every output
+                if x.shape[1] != self.input_dim:
+                    raise ValueError(f"Expected input of shape (B, {self.input_dim}), got {tuple(x.shape)}")
+                return torch.cat([self.jets(x, o)[:, 0:1] for o in range(self.n_out)], dim=1)
             self._engine_for(x.device)
             if x.shape[1] != self.input_dim:
                 raise ValueError(f"Expected input of shape (B, {self.input_dim}), got {tuple(x.shape)}")

@@ -16,8 +16,9 @@ constants and return shapes.  None of the DV trainers uses them; they run on any
 user-composed models around ``DVQuantumLayer`` (whose ``create_graph=True`` reverse pass supplies the
 second derivatives).  For a two-input ``DVPDESolver`` (``classic_network = [2, H, 1]``) the three scalar
 second-order operators (Klein-Gordon, wave, Helmholtz) take their second derivatives from the fused
-derivative-channel kernels (``DVPDESolver.second_order``: any qubit count, both encodings); the three-output
-Navier-Stokes operator stays on the autograd formulation.
+derivative-channel kernels (``DVPDESolver.second_order``: any qubit count, both encodings); for a three-output
+``DVPDESolver`` (``classic_network = [3, H, 3]``) the Navier-Stokes operator takes the six derivative channels of
+u, v and p from the same kernels (``DVPDESolver.jets``) and forms the momentum equations' products in torch.
 """
 import torch
 
@@ -58,6 +59,17 @@ def navier_stokes_2D_operator(model, t, x, y, min_x=0, max_x=1):
     with viscosity 0.00345 and density 1056 (the reference's constants)."""
     viscosity, density = 0.00345, 1056.0
     _track(t, x, y)
+    jets = getattr(model, "jets", None)
+    if jets is not None and getattr(model, "n_out", 0) == 3 and getattr(model, "input_dim", 0) == 3:
+        # a three-output DVPDESolver: the six derivative channels of u, v and p from the fused kernels, the
+        # products of the momentum equations formed here (columns: value, t, x, y, xx, yy)
+        X = torch.cat((t, x, y), 1)
+        U, V, P = jets(X, 0), jets(X, 1), jets(X, 2)
+        c = lambda J, k: J[:, k:k + 1]
+        u, v = c(U, 0), c(V, 0)
+        f_u = c(U, 1) + (u * c(U, 2) + v * c(U, 3)) + c(P, 2) / density - viscosity * (c(U, 4) + c(U, 5))
+        f_v = c(V, 1) + (u * c(V, 2) + v * c(V, 3)) + c(P, 3) / density - viscosity * (c(V, 4) + c(V, 5))
+        return [c(U, 2) + c(V, 3), f_u, f_v]
     fields = model(torch.cat((t, x, y), 1))
     u, v, p = fields[:, 0:1], fields[:, 1:2], fields[:, 2:3]
     mom = []

@@ -17,10 +17,10 @@ pytestmark = pytest.mark.gpu
 NAME_MAP = {"pre": "preprocessor", "post": "postprocessor", "q": "quantum_layer"}
 
 
-def _solver_from_fixture(z, name, device, tmp_path):
+def _solver_from_fixture(z, name, device, tmp_path, network=(2, 16, 1)):
     Solver = pkg("nn.DVPDESolver").DVPDESolver
     torch.manual_seed(0)
-    model = Solver(base_args(classic_network=[2, 16, 1]), Log(tmp_path), device=device)
+    model = Solver(base_args(classic_network=list(network)), Log(tmp_path), device=device)
     prefix = f"{name}__w__"
     sd = {}
     for k in z.files:
@@ -33,11 +33,11 @@ def _solver_from_fixture(z, name, device, tmp_path):
     return model, sd
 
 
-def _ref_grad(z, name, model):
+def _ref_grad(z, name, model, n_in=2, n_out=1):
     """the fixture's gradient (composite order: pre, q, post) re-ordered to model.parameters() order"""
     g = z[f"{name}__grad"]
-    shapes = {"pre.0.weight": (16, 2), "pre.0.bias": (16,), "pre.2.weight": (4, 16), "pre.2.bias": (4,), "q.params": (1, 12),
-              "post.0.weight": (16, 4), "post.0.bias": (16,), "post.2.weight": (1, 16), "post.2.bias": (1,)}
+    shapes = {"pre.0.weight": (16, n_in), "pre.0.bias": (16,), "pre.2.weight": (4, 16), "pre.2.bias": (4,), "q.params": (1, 12),
+              "post.0.weight": (16, 4), "post.0.bias": (16,), "post.2.weight": (n_out, 16), "post.2.bias": (n_out,)}
     off, by = 0, {}
     for k, shp in shapes.items():
         n = int(np.prod(shp))
@@ -81,3 +81,58 @@ def test_two_input_model_refuses_three_columns(gpu_device, tmp_path):
         model(torch.rand(4, 3, device=gpu_device))
     with pytest.raises(ValueError):
         model.residual(torch.rand(4, 3, device=gpu_device))
+
+
+def test_navier_stokes_on_fused_channels_matches_reference(gpu_device, tmp_path):
+    """Reference nn/pde.py:2-27 on a three-output model (u, v, p): the six derivative channels of every output come
+    from the fused kernels (DVPDESolver.jets, qc_post modes 4 / 3 with a cotangent per channel), the products
+    u u_x + v u_y of the momentum equations are formed in torch.  Fixture: the reference's own operator on the CPU
+    oracle (Linear(3,16)-Tanh-Linear(16,4) -> <Z> -> Linear(4,16)-Tanh-Linear(16,3))."""
+    name = "navier_stokes"
+    z = np.load(os.path.join(GOLDEN, "other_operators.npz"))
+    pde = pkg("nn.pde")
+    model, _ = _solver_from_fixture(z, name, gpu_device, tmp_path, network=(3, 16, 3))
+    assert model.postprocessor[2].weight.shape == (3, 16) and model.n_out == 3
+    X = torch.from_numpy(z[f"{name}__X"]).to(gpu_device)
+    cols = [X[:, i:i + 1].clone() for i in range(3)]
+    res = list(pde.navier_stokes_2D_operator(model, *cols))
+    assert len(res) == 3
+    for i, r in enumerate(res):
+        want = z[f"{name}__out{i}"]
+        assert np.abs(r.detach().cpu().numpy() - want).max() < 1e-4 * max(1.0, np.abs(want).max()), i
+    loss = sum((r ** 2).mean() * (i + 1) for i, r in enumerate(res))
+    assert abs(loss.item() - float(z[f"{name}__loss"])) < 1e-4 * max(1.0, float(z[f"{name}__loss"]))
+    model.zero_grad()
+    loss.backward()
+    ref = _ref_grad(z, name, model, n_in=3, n_out=3)
+    gs = max(1.0, max(np.abs(v).max() for v in ref.values()))
+    for pname, p in model.named_parameters():
+        assert np.abs(p.grad.cpu().numpy() - ref[pname]).max() < 2e-4 * gs, pname
+    # the model's forward is the value channel of the three outputs
+    with torch.no_grad():
+        f = model(X)
+    assert f.shape == (X.shape[0], 3)
+    J = [model.jets(X, o) for o in range(3)]
+    assert max((f[:, o] - J[o][:, 0]).abs().max().item() for o in range(3)) < 1e-6
+    with pytest.raises(NotImplementedError):
+        model.residual(X)
+
+
+def test_jets_of_a_single_output_model_agree_with_the_residual_path(gpu_device, tmp_path):
+    """DVPDESolver.jets on the convection-diffusion model: u and the operator's linear combination of the channels
+    equal DVPDESolver.residual (the same kernels behind qc_post modes 0 and 4), and so do the gradients."""
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    torch.manual_seed(3)
+    model = Solver(base_args(), Log(tmp_path), device=gpu_device)
+    X = torch.rand(100, 3, device=gpu_device)
+    D, vx, vy = 0.01, 1.0, 1.0
+    u0, r0 = model.residual(X, D=D, v_x=vx, v_y=vy)
+    J = model.jets(X)
+    r1 = J[:, 1:2] + vx * J[:, 2:3] + vy * J[:, 3:4] - D * (J[:, 4:5] + J[:, 5:6])
+    assert (J[:, 0:1] - u0).abs().max().item() < 1e-6
+    assert (r1 - r0).abs().max().item() < 1e-5 * max(1.0, r0.abs().max().item())
+    w = torch.randn(100, 1, device=gpu_device)
+    g0 = torch.autograd.grad((r0 * w).sum() + (u0 * w).sum(), list(model.parameters()))
+    g1 = torch.autograd.grad((r1 * w).sum() + (J[:, 0:1] * w).sum(), list(model.parameters()))
+    scale = max(1.0, max(g.abs().max().item() for g in g0))
+    assert max((a - b).abs().max().item() for a, b in zip(g0, g1)) < 2e-5 * scale
