@@ -159,6 +159,10 @@ def test_wave_family_ragged_batches_kept_equals_recompute(over, B, gpu_device):
     fs.X_val[:X_ic.shape[0]] = X_ic.to(dev)
     fs.X_val[X_ic.shape[0]:X_ic.shape[0] + X_bc.shape[0]] = X_bc.to(dev)
     assert int(fs.desc.circ_ws_bytes) > 0, "this case must have a kept-state store"
+    # the store's rows of dead points are never written: poison them, a kernel that multiplies them by its zero
+    # cotangents instead of masking them would turn the whole gradient into NaN
+    nfl = fs.step_ws.numel() // 4
+    fs.step_ws[: 4 * nfl].view(torch.float32).fill_(float("nan"))
     fs.run(L.QC_PHASE_GRADS)
     torch.cuda.synchronize()
     kept = fs.flat_grad.clone()
