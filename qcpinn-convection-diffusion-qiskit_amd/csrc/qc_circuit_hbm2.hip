@@ -57,17 +57,20 @@ struct H2Dev {
   int nx = 0, nc = 0;
 };
 
-// LDS swizzle of a local index (8-byte slots; a half-wave of 32 lanes must hit 32 distinct slots mod 32).  The lanes of
-// a round vary the local positions outside its register group; linear maps of the low 5 bits chosen so that every
-// group pattern of the tile (and the linear load / store pattern) is conflict-free:
-//   RB = 4 (groups {0-3}, {4-7}, {8-11}):          low5 ^= idx[5..8], bit 4 ^= idx[8]
-//   RB = 3 (groups {0-2}, {3-5}, {6-8}, {9-11}):   bit 2 ^= idx5, bits {0, 3} ^= idx6, bits {1, 4} ^= idx7
+// LDS swizzle of a local index (8-byte slots).  The lanes of a round vary the local positions outside its register
+// group; a GF(2)-linear map of the low 5 bits chosen so that every group pattern of the tile (and the linear load /
+// store pattern) is conflict-free under BOTH banking rules of the 64-bit accesses: ds_read_b64 serves a wave as two
+// halves of 32 lanes over 64 dword banks (32 distinct slots mod 32), ds_write_b64 as four quarters of 16 lanes over 32
+// dword banks (16 distinct slots mod 16).  Low-5 image of position p (unit vectors for p < 4):
+//   RB = 4 (groups {0-3}, {4-7}, {8-11}):          4 -> 17, 5 -> 2, 6 -> 4, 7 -> 8, 8 -> 16   = low5 ^ idx[4..8]
+//   RB = 3 (groups {0-2}, {3-5}, {6-8}, {9-11}):   4 -> 17, 5 -> 18, 6 -> 12, 7 -> 16
+// (tools/lds_bank_check.py replays every round pattern against both rules.)
 template <int RB>
-__device__ __forceinline__ int h2_swz(int l) {
+__host__ __device__ __forceinline__ constexpr int h2_swz(int l) {
   if constexpr (RB == 3)
-    return l ^ (((l >> 5) & 1) << 2) ^ (((l >> 6) & 1) * 9) ^ (((l >> 7) & 1) * 18);
+    return l ^ ((l >> 4) & 1) ^ (((l >> 5) & 1) * 18) ^ (((l >> 6) & 1) * 12) ^ (((l >> 7) & 1) * 16);
   else
-    return l ^ ((l >> 5) & 15) ^ (((l >> 8) & 1) << 4);
+    return l ^ ((l >> 4) & 31);
 }
 __device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ Cplx cmulc(Cplx a, Cplx b) { return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }

@@ -18,7 +18,7 @@
 //     t[k] = sum_channels Im(conj(lam_k) chi_k) (weights 0, 1, 2 only), formed per tile in LDS.
 // The plan is plain data (no HIP types) so that it can be inspected from tests (qc_hbm_plan_describe).
 #pragma once
-#include "qc_common.h"
+#include "qc_types.h"
 
 #include <algorithm>
 #include <vector>
@@ -149,7 +149,11 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
       for (int j = 0; j < G; ++j)
         if (h2_is_diag(gate(j).op) && ready(j)) run.push_back(j);
       if (!run.empty()) {
-        const bool as_table = (int)run.size() >= H2_TABLE_MIN;
+        // a table pays for runs with controlled phases (one multiply instead of one per gate); a run of plain RZ gates
+        // rides in the rounds that hold their bits in registers
+        bool has_ctl = false;
+        for (int j : run) has_ctl = has_ctl || gate(j).op == QC_CRZ;
+        const bool as_table = (int)run.size() >= H2_TABLE_MIN && has_ctl;
         bool ok = true;
         if (as_table) {
           ok = ntab < H2_MAXTAB;
@@ -219,7 +223,12 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
       auto it = std::find(loc.begin(), loc.end(), b);
       return it == loc.end() ? -1 : (int)(it - loc.begin());
     };
-    // ---- rounds.  Standard register groups: positions [k RB, k RB + RB); the last one overlaps if nloc % RB != 0.
+    // ---- rounds: list scheduling.  Standard register groups: positions [k RB, k RB + RB); the last one overlaps if
+    // nloc % RB != 0.  A gate joins the EARLIEST round that (a) comes no earlier than its predecessors and (b) holds its
+    // target (a two-wire unitary: both bits) among the register bits - gates that do not depend on each other share a
+    // round whatever their distance in the program (e.g. RX(b), RZ(b), then the fixed unitary on (b, b')); only when no
+    // such round exists a new one is opened at the end.  Positions in time: 3 r + {0: table applied as round r loads,
+    // 1: gates of round r, 2: table applied before round r stores}.
     const int RB = P.rbits;
     auto group_of = [&](int p0, int p1, int (&rb)[4]) {   // a register set containing positions p0 (and p1 >= 0)
       const int ngrp = (sd.nloc + RB - 1) / RB;
@@ -231,24 +240,53 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
           return;
         }
       }
-      // no standard group holds both: p0, p1 and the lowest other positions
+      // no standard group holds both: p0, p1 and other positions, those above the always-local low bits first (a round
+      // whose register bits all lie above them can read / write HBM in its own mapping)
       std::vector<int> s = {p0, p1};
-      for (int p = 0; p < sd.nloc && (int)s.size() < RB; ++p)
+      for (int p = LOW; p < sd.nloc && (int)s.size() < RB; ++p)
+        if (p != p0 && p != p1) s.push_back(p);
+      for (int p = 0; p < LOW && p < sd.nloc && (int)s.size() < RB; ++p)
         if (p != p0 && p != p1) s.push_back(p);
       std::sort(s.begin(), s.end());
       for (int q = 0; q < RB; ++q) rb[q] = s[q];
     };
-    sd.r0 = (int)P.rounds.size();
+    struct RoundB {
+      H2Round r;
+      std::vector<H2Gate> g;
+      std::vector<int> gid;          // program index (relative to g_first) of every gate of the round
+      std::vector<int> tab_gid_pre, tab_gid_post;
+      int np;
+    };
+    std::vector<RoundB> RS;
+    std::vector<int> when(G, -1);    // time of every gate scheduled in this stage
     sd.np = 0;
     sd.ntab = 0;
-    bool open = false;
-    int open_np = 0;
     auto in_rb = [&](const H2Round& r, int p) {
       for (int q = 0; q < r.nrb; ++q)
         if (r.rb[q] == p) return q;
       return -1;
     };
-    int pend_tab = -1, pend_ts = -1;   // a table waiting for the next gate round (becomes its tab_pre)
+    auto tmin_of = [&](const std::vector<int>& js) {
+      int t = -1;
+      for (int j : js)
+        for (int i : pred[j])
+          if (state[i] == 1 && when[i] > t) t = when[i];
+      return t;
+    };
+    auto new_round = [&](const int (&want)[4]) {
+      RoundB nb;
+      nb.r = {};
+      nb.r.kind = H2_ROUND_GATES;
+      nb.r.nrb = RB;
+      for (int q = 0; q < RB; ++q) nb.r.rb[q] = want[q];
+      nb.r.table = nb.r.tslot = -1;
+      nb.r.tab_pre = nb.r.ts_pre = nb.r.tab_post = nb.r.ts_post = -1;
+      nb.np = 0;
+      RS.push_back(nb);
+      return (int)RS.size() - 1;
+    };
+    int pend_tab = -1, pend_ts = -1;   // a table without predecessors, waiting for the stage's first round (its tab_pre)
+    std::vector<int> pend_gid;
     for (const Item& it : items) {
       if (it.kind == 1) {
         const int table = (int)P.tables.size(), tslot = sd.ntab;
@@ -260,18 +298,32 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
           P.dgates.push_back({g.op, ctl ? g.bb : g.ba, ctl ? g.ba : -1, g_first + j, g.slot});
         }
         P.tables.push_back(tb);
-        if (pend_tab >= 0) {   // two tables in a row cannot happen (diagonal runs merge); keep the plan valid anyway
-          H2Round r = {};
-          r.kind = H2_ROUND_TABLE;
-          r.table = pend_tab;
-          r.tslot = pend_ts;
-          r.tab_pre = r.tab_post = r.ts_pre = r.ts_post = -1;
-          sd.tab_round[pend_ts] = (int)P.rounds.size() - sd.r0;
-          P.rounds.push_back(r);
+        const int tmin = tmin_of(it.g);
+        int tnow;
+        if (RS.empty() && pend_tab < 0) {
+          pend_tab = table;
+          pend_ts = tslot;
+          pend_gid = it.g;
+          tnow = 0;
+        } else if (!RS.empty() && RS.back().r.kind == H2_ROUND_GATES && RS.back().r.tab_post < 0 &&
+                   tmin <= 3 * ((int)RS.size() - 1) + 1) {
+          RS.back().r.tab_post = table;
+          RS.back().r.ts_post = tslot;
+          RS.back().tab_gid_post = it.g;
+          tnow = 3 * ((int)RS.size() - 1) + 2;
+        } else {   // a round of its own (element-wise pass over the tile in LDS)
+          RoundB nb;
+          nb.r = {};
+          nb.r.kind = H2_ROUND_TABLE;
+          nb.r.table = table;
+          nb.r.tslot = tslot;
+          nb.r.tab_pre = nb.r.ts_pre = nb.r.tab_post = nb.r.ts_post = -1;
+          nb.np = 0;
+          nb.gid = it.g;
+          RS.push_back(nb);
+          tnow = 3 * ((int)RS.size() - 1) + 1;
         }
-        pend_tab = table;
-        pend_ts = tslot;
-        open = false;
+        for (int j : it.g) when[j] = tnow;
         continue;
       }
       const int j = it.g[0];
@@ -295,49 +347,34 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
       }
       const int tp = pos(hg.tbit), cp = hg.cbit >= 0 ? pos(hg.cbit) : -1;
       const bool par = h2_is_param(g.op);
-      // which register set does it need?
-      int want[4] = {-1, -1, -1, -1};
-      bool need_set = false;
-      if (h2_is_diag(g.op)) {
-        need_set = false;            // rides along in whatever round is open
-      } else if (g.op == QC_U4) {
-        group_of(tp, cp, want);
-        need_set = true;
-      } else {
-        group_of(tp, -1, want);
-        need_set = true;
+      const bool diag = h2_is_diag(g.op);
+      const int tmin = tmin_of(it.g);
+      const int rmin = tmin <= 1 ? 0 : (tmin + 1) / 3;   // smallest r with 3 r + 1 >= tmin
+      auto room = [&](const RoundB& rbk) {
+        return rbk.r.kind == H2_ROUND_GATES && (int)rbk.g.size() < H2_MAXRG && !(par && rbk.np >= H2_MAXRP);
+      };
+      int at = -1;
+      for (int r = rmin; r < (int)RS.size() && at < 0; ++r) {
+        if (!room(RS[r])) continue;
+        const bool t_in = tp >= 0 && in_rb(RS[r].r, tp) >= 0, c_in = cp >= 0 && in_rb(RS[r].r, cp) >= 0;
+        if (g.op == QC_U4 ? (t_in && c_in) : (diag && ctl ? (t_in && c_in) : t_in)) at = r;
       }
-      bool fits = open && (int)(P.rounds.back().ng) < H2_MAXRG && !(par && open_np >= H2_MAXRP);
-      if (fits && need_set) {
-        const H2Round& r = P.rounds.back();
-        fits = in_rb(r, tp) >= 0 && (g.op != QC_U4 || in_rb(r, cp) >= 0);
+      if (at < 0 && diag)   // a diagonal gate rides in any round as a phase multiply by index bits
+        for (int r = rmin; r < (int)RS.size() && at < 0; ++r)
+          if (room(RS[r])) at = r;
+      if (at < 0) {
+        int want[4] = {-1, -1, -1, -1};
+        if (g.op == QC_U4) group_of(tp, cp, want);
+        else group_of(tp >= 0 ? tp : 0, -1, want);
+        at = new_round(want);
       }
-      if (!fits) {
-        H2Round r = {};
-        r.kind = H2_ROUND_GATES;
-        r.nrb = RB;
-        if (!need_set) group_of(tp >= 0 ? tp : 0, -1, want);
-        for (int q = 0; q < RB; ++q) r.rb[q] = want[q];
-        r.g0 = (int)P.gates.size();
-        r.ng = 0;
-        r.table = -1;
-        r.tslot = -1;
-        r.tab_pre = pend_tab;
-        r.ts_pre = pend_ts;
-        r.tab_post = r.ts_post = -1;
-        if (pend_tab >= 0) sd.tab_round[pend_ts] = (int)P.rounds.size() - sd.r0;
-        pend_tab = pend_ts = -1;
-        P.rounds.push_back(r);
-        open = true;
-        open_np = 0;
-      }
-      H2Round& r = P.rounds.back();
-      const int tq = tp >= 0 ? in_rb(r, tp) : -1, cq = cp >= 0 ? in_rb(r, cp) : -1;
+      RoundB& rbk = RS[at];
+      const int tq = tp >= 0 ? in_rb(rbk.r, tp) : -1, cq = cp >= 0 ? in_rb(rbk.r, cp) : -1;
       if (g.op == QC_U4) {
         hg.kind = H2_K_U4;
         hg.tq = tq;
         hg.cq = cq;
-      } else if (h2_is_diag(g.op) && (tq < 0 || (ctl && cq < 0))) {
+      } else if (diag && (tq < 0 || (ctl && cq < 0))) {
         hg.kind = H2_K_PHASE;
       } else if (ctl) {
         hg.tq = tq;
@@ -352,26 +389,79 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
         hg.tq = tq;
       }
       if (par) {
-        hg.pidx = sd.np++;
-        ++open_np;
+        hg.pidx = 0;   // numbered when the rounds are laid out
+        ++rbk.np;
       }
-      P.gates.push_back(hg);
-      ++r.ng;
+      rbk.g.push_back(hg);
+      rbk.gid.push_back(j);
+      when[j] = 3 * at + 1;
     }
-    if (pend_tab >= 0) {   // the stage ends with a table: after the last gate round, or alone
-      if ((int)P.rounds.size() > sd.r0 && P.rounds.back().kind == H2_ROUND_GATES) {
-        P.rounds.back().tab_post = pend_tab;
-        P.rounds.back().ts_post = pend_ts;
-        sd.tab_round[pend_ts] = (int)P.rounds.size() - 1 - sd.r0;
+    // the pending first table: tab_pre of the first round if that is a gate round, else a round of its own in front
+    if (pend_tab >= 0) {
+      if (!RS.empty() && RS[0].r.kind == H2_ROUND_GATES && RS[0].r.tab_pre < 0) {
+        RS[0].r.tab_pre = pend_tab;
+        RS[0].r.ts_pre = pend_ts;
+        RS[0].tab_gid_pre = pend_gid;
       } else {
-        H2Round r = {};
-        r.kind = H2_ROUND_TABLE;
-        r.table = pend_tab;
-        r.tslot = pend_ts;
-        r.tab_pre = r.tab_post = r.ts_pre = r.ts_post = -1;
-        sd.tab_round[pend_ts] = (int)P.rounds.size() - sd.r0;
-        P.rounds.push_back(r);
+        RoundB nb;
+        nb.r = {};
+        nb.r.kind = H2_ROUND_TABLE;
+        nb.r.table = pend_tab;
+        nb.r.tslot = pend_ts;
+        nb.r.tab_pre = nb.r.ts_pre = nb.r.tab_post = nb.r.ts_post = -1;
+        nb.np = 0;
+        nb.gid = pend_gid;
+        RS.insert(RS.begin(), nb);
       }
+    }
+    // ---- round order: the stage's last round stores straight to HBM (and the adjoint sweep starts straight from HBM)
+    // when its register bits lie above the always-local low bits.  If the last round cannot, move one that can behind
+    // it, provided nothing scheduled after it depends on it.
+    auto direct_ok = [&](const RoundB& rbk) { return rbk.r.kind == H2_ROUND_GATES && rbk.r.rb[0] >= LOW; };
+    if ((int)RS.size() >= 2 && !direct_ok(RS.back())) {
+      for (int k = (int)RS.size() - 2; k >= 0; --k) {
+        if (!direct_ok(RS[k]) || RS[k].r.tab_post >= 0) continue;
+        if (RS[k].r.tab_pre >= 0 && !(k == 0 && RS[1].r.kind == H2_ROUND_GATES && RS[1].r.tab_pre < 0)) continue;
+        bool legal = true;
+        auto depends = [&](const std::vector<int>& js) {
+          for (int j : js)
+            for (int i : pred[j])
+              if (std::find(RS[k].gid.begin(), RS[k].gid.end(), i) != RS[k].gid.end()) return true;
+          return false;
+        };
+        for (int r = k + 1; r < (int)RS.size() && legal; ++r)
+          legal = !depends(RS[r].gid) && !depends(RS[r].tab_gid_pre) && !depends(RS[r].tab_gid_post);
+        if (!legal) continue;
+        RoundB mv = RS[k];
+        if (mv.r.tab_pre >= 0) {   // the stage's first table stays in front
+          RS[1].r.tab_pre = mv.r.tab_pre;
+          RS[1].r.ts_pre = mv.r.ts_pre;
+          RS[1].tab_gid_pre = mv.tab_gid_pre;
+          mv.r.tab_pre = mv.r.ts_pre = -1;
+          mv.tab_gid_pre.clear();
+        }
+        RS.erase(RS.begin() + k);
+        RS.push_back(mv);
+        break;
+      }
+    }
+    // ---- lay the rounds out
+    sd.r0 = (int)P.rounds.size();
+    for (int r = 0; r < (int)RS.size(); ++r) {
+      RoundB& rbk = RS[r];
+      if (rbk.r.kind == H2_ROUND_TABLE) {
+        sd.tab_round[rbk.r.tslot] = r;
+      } else {
+        if (rbk.r.tab_pre >= 0) sd.tab_round[rbk.r.ts_pre] = r;
+        if (rbk.r.tab_post >= 0) sd.tab_round[rbk.r.ts_post] = r;
+        rbk.r.g0 = (int)P.gates.size();
+        rbk.r.ng = (int)rbk.g.size();
+        for (H2Gate& hg : rbk.g) {
+          if (h2_is_param(hg.op)) hg.pidx = sd.np++;
+          P.gates.push_back(hg);
+        }
+      }
+      P.rounds.push_back(rbk.r);
     }
     sd.nr = (int)P.rounds.size() - sd.r0;
     for (int b = 0; b < 24; ++b) sd.where[b] = 0;
