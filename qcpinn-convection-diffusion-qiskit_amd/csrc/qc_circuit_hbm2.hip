@@ -18,30 +18,14 @@
 // HBM traffic per channel-evaluation at n = 16 cross_mesh (2 stages): forward 1 write + 1 read + 1 write (kept
 // final state), backward 1 read + 2 writes + 2 reads  ->  8 state transfers for forward + adjoint against the
 // SURVEY §8(d) minimum of 4; the round-1 kernels moved ~56.
-#include "qc_internal.h"
-#include "qc_gates.h"
-#include "qc_hbm2_plan.h"
+#include "qc_circuit_h2s_kernels.h"
 
 #include <stdlib.h>
 #include <string.h>
 
 #include <vector>
 
-// Diagnostic, timing-only builds (results are wrong): -DH2_ABLATE_GATES skips the gate arithmetic of the rounds,
-// -DH2_ABLATE_SYNC drops the block barriers of the stage kernel.  Never defined for the shipped library.
-#ifdef H2_ABLATE_SYNC
-#define H2_SYNC() __builtin_amdgcn_wave_barrier()
-#else
-#define H2_SYNC() __syncthreads()
-#endif
-
 namespace {
-
-struct Cplx {
-  float re, im;
-};
-
-constexpr int H2_XW = 24;   // floats per <Z> partial record (n <= 20 used)
 
 // ---- device copy of the plan
 struct H2Dev {
@@ -55,25 +39,8 @@ struct H2Dev {
   int* d_pslots = nullptr;      // per stage: parameter slot of in-round parametric gate pidx; offsets in pslot_off
   std::vector<int> pslot_off;
   int nx = 0, nc = 0;
+  const H2sLaunchers* stat = nullptr;   // compile-time stage programs of exactly this plan (gen/qc_static_h2_*.hip), or null
 };
-
-// LDS swizzle of a local index (8-byte slots).  The lanes of a round vary the local positions outside its register
-// group; a GF(2)-linear map of the low 5 bits chosen so that every group pattern of the tile (and the linear load /
-// store pattern) is conflict-free under BOTH banking rules of the 64-bit accesses: ds_read_b64 serves a wave as two
-// halves of 32 lanes over 64 dword banks (32 distinct slots mod 32), ds_write_b64 as four quarters of 16 lanes over 32
-// dword banks (16 distinct slots mod 16).  Low-5 image of position p (unit vectors for p < 4):
-//   RB = 4 (groups {0-3}, {4-7}, {8-11}):          4 -> 17, 5 -> 2, 6 -> 4, 7 -> 8, 8 -> 16   = low5 ^ idx[4..8]
-//   RB = 3 (groups {0-2}, {3-5}, {6-8}, {9-11}):   4 -> 17, 5 -> 18, 6 -> 12, 7 -> 16
-// (tools/lds_bank_check.py replays every round pattern against both rules.)
-template <int RB>
-__host__ __device__ __forceinline__ constexpr int h2_swz(int l) {
-  if constexpr (RB == 3)
-    return l ^ ((l >> 4) & 1) ^ (((l >> 5) & 1) * 18) ^ (((l >> 6) & 1) * 12) ^ (((l >> 7) & 1) * 16);
-  else
-    return l ^ ((l >> 4) & 31);
-}
-__device__ __forceinline__ Cplx cmul(Cplx a, Cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
-__device__ __forceinline__ Cplx cmulc(Cplx a, Cplx b) { return {a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; }
 
 // ---------------------------------------------------------------- per-point, per-wire embedding data
 // wd[pt][w][8] = {cos, sin of (a_w + theta_w)/2, da_t, da_x, da_y, dda_xx, dda_yy, 0}, pt = point within the launch group
@@ -116,48 +83,7 @@ __global__ void __launch_bounds__(256) k_h2_diag_table(const H2DiagGate* __restr
   tab[k] = {(float)zr, (float)zi};
 }
 
-// ---------------------------------------------------------------- stage kernel
-struct H2Args {
-  Cplx* store;           // tile slots
-  int64_t slot_elems;    // complex64 elements per slot = 2 * nch * 64 * 2^n
-  int64_t B;             // points of the call ([feature][B] arrays)
-  int64_t p_first;       // point index of (tile 0, t = 0) of this launch
-  int64_t pt_stride;     // points covered by this launch rounded up to 64 (row stride of the partial buffers)
-  int n;
-  int first, last;       // this stage is the first / last of the plan
-  int keep_final;        // forward, last stage: leave the final states in the slot
-  H2Stage sd;
-  const H2Round* rounds;
-  const H2Gate* gates;
-  const QcTrig* trig;
-  const float* umat;
-  const Cplx* tabs;      // [n_tables][2^n]
-  const float* wd;       // [pt_stride][n][8]
-  float* xpart;          // forward, last stage: [8][pt_stride][ntau][H2_XW]
-  const float* qbar;     // backward, last stage: [nch][n][B]
-  float* gpart;          // backward: [np][pt_stride * ntau] partials of the in-round parametric gates
-  float* dpart;          // backward: [ntab][pt_stride * ntau][nc] Walsh-Hadamard coefficients of t
-  Cplx* xi;              // backward, first stage: [nch][pt_stride][ntau][nx] un-embedded cotangents, weight <= 3
-  const int* sparse_idx;
-  const int* wht_idx;
-  int nx, nc;
-};
-
-// Plan records are read with wave-uniform addresses; readfirstlane tells the compiler so (SGPRs instead of VGPRs for
-// every index, offset and coefficient derived from them).
-__device__ __forceinline__ int h2_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float h2_unif(float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
-}
-// Read-only plan / coefficient records through the constant address space with a wave-uniform pointer: scalar loads
-// (s_load_dwordxN into SGPRs) instead of per-lane global loads followed by readfirstlane.
-template <class T>
-__device__ __forceinline__ const __attribute__((address_space(4))) T* h2_const(const T* p) {
-  const unsigned long long u = (unsigned long long)p;
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
-  return (const __attribute__((address_space(4))) T*)(((unsigned long long)hi << 32) | lo);
-}
+// ---------------------------------------------------------------- stage kernel (run-time plan)
 __device__ __forceinline__ H2Round h2_load_round(const H2Round* p) {
   const auto* c = h2_const(p);
   H2Round r;
@@ -1144,10 +1070,50 @@ static int h2_rb12() {
   return rb12;
 }
 
+// generated plans (gen/qc_static_h2_table.hip)
+struct QcStaticH2Entry {
+  int n_qubits, n_gates, absorb, rb;
+  const int* gates;      // n_gates x 4: (op, ba, bb, slot) in the device encoding
+  const int* describe;   // h2_describe() of the plan the kernels were generated from
+  int n_describe;
+  const H2sLaunchers* launch;
+};
+extern const QcStaticH2Entry qc_static_h2_table[];
+extern const int qc_static_h2_count;
+
+// the generated entry for this program, or -1.  QC_NO_STATIC=1: none; QC_H2S_RB=3|4: only entries of that geometry
+static int h2s_match(const qc_program* pg, int absorb) {
+  static const bool off = [] { const char* e = getenv("QC_NO_STATIC"); return e && e[0] == '1'; }();
+  static const int want_rb = [] { const char* e = getenv("QC_H2S_RB"); return e ? atoi(e) : 0; }();
+  if (off) return -1;
+  for (int i = 0; i < qc_static_h2_count; ++i) {
+    const QcStaticH2Entry& e = qc_static_h2_table[i];
+    if (e.n_qubits != pg->n_qubits || e.n_gates != pg->n_gates || e.absorb != absorb) continue;
+    if (want_rb && e.rb != want_rb) continue;
+    bool same = true;
+    for (int g = 0; g < pg->n_gates && same; ++g) {
+      const QcGate& a = pg->h_gates[g];
+      const int* b = e.gates + 4 * g;
+      same = a.op == b[0] && a.ba == b[1] && a.bb == b[2] && a.slot == b[3];
+    }
+    if (same) return i;
+  }
+  return -1;
+}
+
 void* qc_h2_create(const qc_program* pg, int absorb) {
   QcH2* h = new QcH2();
   H2Dev& D = h->dev;
-  D.plan = h2_make_plan(pg->h_gates, pg->n_gates, pg->n_qubits, absorb, h2_rb12());
+  const int sid = h2s_match(pg, absorb);
+  if (sid >= 0) {
+    // the kernels were generated from the plan of the SAME planner at build time: trust them only if the plan built
+    // now is identical, record by record
+    const QcStaticH2Entry& e = qc_static_h2_table[sid];
+    D.plan = h2_make_plan(pg->h_gates, pg->n_gates, pg->n_qubits, absorb, e.rb);
+    const std::vector<int> d = h2_describe(D.plan);
+    if ((int)d.size() == e.n_describe && memcmp(d.data(), e.describe, sizeof(int) * d.size()) == 0) D.stat = e.launch;
+  }
+  if (!D.stat) D.plan = h2_make_plan(pg->h_gates, pg->n_gates, pg->n_qubits, absorb, h2_rb12());
   const H2Plan& P = D.plan;
   const int nl0 = P.stages[0].nloc;
   std::vector<int> rank((size_t)1 << nl0, -1);
@@ -1265,12 +1231,9 @@ static void h2_launch_stage(const H2Args& A, int64_t npts64, hipStream_t st) {
   const int nloc = A.sd.nloc;
   const int NT = (1 << nloc) >> RB;
   const size_t sh = sizeof(Cplx) * ((size_t)1 << nloc) * (MODE == 1 ? 2 : 1);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_stage<RB, NCH, MODE, ROLE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    attr = true;
-  }
+  // the attribute is per device: set before every launch (cheap), not once per process
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_stage<RB, NCH, MODE, ROLE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
   const unsigned grid = (unsigned)(npts64 << A.sd.ngb);
   hipLaunchKernelGGL((k_h2_stage<RB, NCH, MODE, ROLE>), dim3(grid), dim3(NT), sh, st, A);
 }
@@ -1341,7 +1304,7 @@ static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, c
       A.first = i == 0;
       A.last = i == S - 1;
       A.keep_final = keep_final ? 1 : 0;
-      h2_launch_stage_rb<NCH, 0>(P.rbits, A, npts64, st);
+      if (!(D.stat && D.stat->stage(NCH, 0, i, A, npts64, st))) h2_launch_stage_rb<NCH, 0>(P.rbits, A, npts64, st);
     }
     if (qjets) {
       const int ntau = 1 << P.stages[S - 1].ngb;
@@ -1357,7 +1320,7 @@ static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, c
     A.sd = P.stages[i];
     A.first = i == 0;
     A.last = i == S - 1;
-    h2_launch_stage_rb<NCH, 1>(P.rbits, A, npts64, st);
+    if (!(D.stat && D.stat->stage(NCH, 1, i, A, npts64, st))) h2_launch_stage_rb<NCH, 1>(P.rbits, A, npts64, st);
     const int ntau = 1 << A.sd.ngb;
     if (A.sd.np > 0)
       hipLaunchKernelGGL(k_h2_fold_gates, dim3(A.sd.np, (unsigned)ntiles), dim3(256), 0, st, w.gpart, npts64 * ntau, 64 * ntau,
@@ -1374,11 +1337,7 @@ static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, c
     const int ntau = 1 << s0.ngb;
     const size_t xb = sizeof(Cplx) * (size_t)ntau * D.nx;
     const int use_lds = xb <= 64 * 1024 ? 1 : 0;
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_abar<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-      attr = true;
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_abar<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     hipLaunchKernelGGL((k_h2_abar<NCH>), dim3((unsigned)npts), dim3(128), use_lds ? xb : 0, st, w.xi, w.xwork, npts64, ntau, D.nx, s0,
                        n, w.wd, D.d_rank, B, p_first, npts, abar, use_lds);
     if (P.absorb)
