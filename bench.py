@@ -193,16 +193,41 @@ def measured_traffic():
         return {}
 
 
-def timed_steps(model_args, global_batch, steps, warmup, dev, dist=None):
+PREROLL_MS = 60.0              # untimed GPU time before the timed region (steady clocks)
+PREROLL_MAX_STEPS = 4096
+
+
+def timed_steps(model_args, global_batch, steps, warmup, dev, dist=None, preroll_ms=0.0, windows=0):
     """`steps` full training steps of one configuration on this rank; returns (seconds, trainer, model, host_s)."""
     Solver = importlib.import_module(PKG + ".nn.DVPDESolver").DVPDESolver
     trainer = importlib.import_module(PKG + ".trainer.diffusion_train")
     torch.manual_seed(1)
     model = Solver(model_args, Log(), device=dev)
-    tr = trainer.FusedTrainer(model, global_batch, capacity=steps + warmup)
+    tr = trainer.FusedTrainer(model, global_batch, capacity=steps * (1 + windows) + warmup + PREROLL_MAX_STEPS)
     for _ in range(warmup):
         tr.sample()
         tr.step()
+    # clock pre-roll (untimed, beyond the W warm-up steps): a short timed region right after an idle GPU measures the
+    # clock ramp, not the kernels.  A 16-step probe gives the pace; the count derived from it is made the same on
+    # every rank (the steps contain a collective).
+    preroll = 0
+    if preroll_ms > 0:
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        for _ in range(16):
+            tr.sample()
+            tr.step()
+        torch.cuda.synchronize()
+        per = (time.perf_counter() - w0) / 16 * 1e3
+        if dist is not None:
+            t = torch.tensor([per], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            per = float(t.item())
+        more = int(min(PREROLL_MAX_STEPS - 16, max(0, round(preroll_ms / max(per, 1e-3)) - 16)))
+        for _ in range(more):
+            tr.sample()
+            tr.step()
+        preroll = 16 + more
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -214,7 +239,23 @@ def timed_steps(model_args, global_batch, steps, warmup, dev, dist=None):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    return time.perf_counter() - t0, tr, model, t_enqueue
+    dt = time.perf_counter() - t0
+    # further windows of K steps each (extra keys of the line: spread of the same measurement)
+    win = []
+    for _ in range(windows):
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        for _ in range(steps):
+            tr.sample()
+            tr.step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        win.append((time.perf_counter() - w0) / steps * 1e3)
+    tr.bench_info = {"preroll_steps": preroll, "window_ms_per_step": win}
+    return dt, tr, model, t_enqueue
 
 
 def other_configs(dev):
@@ -291,6 +332,7 @@ def main():
                     help="residual points per GPU (default: 65536 = config 2 at N = 1, 131072 = config 4's shard at N > 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps (min / median reported beside the line)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -319,7 +361,7 @@ def main():
     per_gpu = a.batch_per_gpu or (65536 if world == 1 else 131072)
     args = base_args()
     global_batch = per_gpu * world
-    dt, tr, model, t_enqueue = timed_steps(args, global_batch, a.steps, a.warmup, dev, dist)
+    dt, tr, model, t_enqueue = timed_steps(args, global_batch, a.steps, a.warmup, dev, dist, preroll_ms=PREROLL_MS, windows=a.windows)
     if dist is not None:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -342,6 +384,7 @@ def main():
         ach = flops[dom] * tr.B_res / (kt[dom] * 1e-3) / 1e12
         step_ms = dt / a.steps * 1e3
         value = a.steps * global_batch / dt
+        wins = [step_ms] + list(tr.bench_info["window_ms_per_step"])     # the timed region + the extra K-step windows
         traffic = measured_traffic() if (world == 1 and per_gpu == 65536) else {}
         step_bytes = sum(v for k, v in traffic.items() if k.startswith("stage_") or k in ("fold_rows", "adam")) or None
         cfg_name = ("BASELINE config 2" if (world == 1 and per_gpu == 65536) else
@@ -349,13 +392,15 @@ def main():
         out = {
             "metric": "collocation-points/sec (PDE+BC+IC loss step), 4-qubit cascade",
             "value": value, "unit": "residual collocation points/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak",
+            "warmup": a.warmup, "ms_per_step": step_ms, "ms_per_step_min": min(wins), "ms_per_step_median": sorted(wins)[len(wins) // 2],
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{cfg_name}: DV solver, 4 qubits, cascade, 1 layer, H=50, "
                                    f"{per_gpu} residual + 2x{per_gpu // 3} BC/IC points per GPU",
                        "global_batch": global_batch, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
                        "total_points_per_s": a.steps * (global_batch + 2 * (global_batch // 3)) / dt,
-                       "final_loss": rec["loss"], "host_enqueue_ms_per_step": t_enqueue / a.steps * 1e3},
+                       "final_loss": rec["loss"], "host_enqueue_ms_per_step": t_enqueue / a.steps * 1e3,
+                       "preroll_steps_untimed": tr.bench_info["preroll_steps"], "windows_ms_per_step": wins},
             "roofline": {"bound": "valu", "pipe": "fp32 VALU (register-resident statevectors: no MFMA, no dense contraction)",
                          "kernel": dom, "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": ach / PEAK_F32_TFLOPS, "traffic": traffic.get(dom),

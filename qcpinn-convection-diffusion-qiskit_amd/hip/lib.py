@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# (QC_LIB: a diagnostic build of the same library, e.g. the timing-only ablation variants of tools/ablate_hbm.sh)
+# (QC_LIB: a diagnostic build of the same library, e.g. one compiled with -DH2_ABLATE_GATES / -DH2_ABLATE_SYNC, csrc/qc_h2_shared.h)
 LIB_PATH = os.environ.get("QC_LIB") or os.path.join(os.path.dirname(_HERE), "libqcpinn_hip.so")
 
 QC_PHASE_GRADS = 1

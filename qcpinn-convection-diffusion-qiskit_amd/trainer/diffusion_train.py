@@ -78,6 +78,13 @@ class FusedTrainer:
         """``n_bc`` (default ``batch_size // 3``): GLOBAL boundary points per step; ``bc_faces`` = 4 spreads them
         evenly over the faces x=0, x=1, y=0, y=1 (second workload, train_hybrid_qpinn.py:689-697) instead of
         the x=0 face; ``pde`` = {"D", "vx", "vy", "problem"} overrides the engine's operator / targets."""
+        # the fused step is the 3-D convection-diffusion step of trainer/diffusion_train.py:30-49 on a (t, x, y) -> u model;
+        # the reference fails on any other shape (Linear(3, H) weight mismatch), and so does this trainer: a two-input
+        # model keeps a zero-padded t column in W1 that the step would train, a K-output model has K last-layer rows
+        if getattr(model, "input_dim", 3) != 3 or getattr(model, "n_out", 1) != 1:
+            raise ValueError("train() / FusedTrainer need classic_network = [3, H, 1] (got input_dim = %s, n_out = %s): the "
+                             "convection-diffusion step takes (t, x, y) points and one output"
+                             % (getattr(model, "input_dim", None), getattr(model, "n_out", None)))
         dev = model._resolve_device(model.device)
         if dev is None or dev.type != "cuda":
             raise _lib.QcError("training a DVPDESolver needs a GPU (HIP kernels, no CPU fallback)")
@@ -140,6 +147,19 @@ class FusedTrainer:
         with torch.cuda.device(self.device):
             _lib.check(lib.qc_comm_create(raw, self.world, self.rank, C.byref(comm)), "qc_comm_create")
         return comm
+
+    def close(self):
+        """Destroys the library-owned RCCL communicator (QC_DP_COLLECTIVE=rccl); idempotent."""
+        comm, self._comm = getattr(self, "_comm", None), None
+        if comm is not None:
+            try:
+                self.fs.set_comm(None)
+                self.eng.lib.qc_comm_destroy(comm)
+            except Exception:        # interpreter shutdown: the library may already be gone
+                pass
+
+    def __del__(self):
+        self.close()
 
     # -- optimiser state: continue from the torch optimiser / scheduler objects of the model
     def _make_opt_state(self, capacity):

@@ -103,6 +103,17 @@ def test_no_cpu_fallback(tmp_path):
         pkg("nn.DVQuantumLayer").DVQuantumLayer(base_args())(torch.rand(5, 4))
 
 
+@pytest.mark.parametrize("net", [[2, 50, 1], [3, 50, 3]])
+def test_train_refuses_models_that_are_not_t_x_y_to_u(net, tmp_path):
+    """The fused step is the (t, x, y) -> u convection-diffusion step (reference trainer/diffusion_train.py:30-49 would
+    fail on the Linear(3, H) shape mismatch): a two-input or a K-output DVPDESolver must not be trained silently."""
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    trainer = pkg("trainer.diffusion_train")
+    model = Solver(base_args(classic_network=net, epochs=1), Log(tmp_path), device=torch.device("cpu"))
+    with pytest.raises(ValueError, match="classic_network"):
+        trainer.train(model, batch_size=16)
+
+
 class Tiny(nn.Module):
     """A duck-typed classical model, like the reference's ClassicalSolver."""
 
