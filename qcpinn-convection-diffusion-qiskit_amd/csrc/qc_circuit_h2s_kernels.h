@@ -102,6 +102,49 @@ struct H2sRound {
   static constexpr bool direct = rd.kind == H2_ROUND_GATES && rd.rb[0] >= 4;   // may talk to HBM in its own mapping
 };
 
+// ---- runs of RZ gates on register bits inside a round: ONE multiply by a 2^RB-entry phase record
+// A round often carries RZ(b) for each of its register bits back to back (after the RX layer of an ansatz).  They are
+// diagonal and commute: their product is one unit phase per register combination q, the same in every lane - a record
+// of 2^RB (re, im) pairs built per parameter update by k_h2s_round_phases and read here as scalar operands.  In the
+// adjoint sweep t_q = Im(conj(lam_q) chi_q) is invariant under the run, so every gate's gradient is a signed sum of the
+// same t (as for the big phase tables).  Runs are numbered in plan order; the host mirrors this enumeration
+// (h2s_enumerate_rz_runs in qc_circuit_hbm2.hip).
+template <class PL>
+struct H2sRz {
+  static constexpr bool rz1(int g) { return PL::gates[g].kind == H2_K_REG1 && PL::gates[g].op == QC_RZ; }
+  static constexpr int round_of(int g) {
+    for (int r = 0; r < PL::NROUNDS; ++r)
+      if (PL::rounds[r].kind == H2_ROUND_GATES && g >= PL::rounds[r].g0 && g < PL::rounds[r].g0 + PL::rounds[r].ng) return r;
+    return 0;
+  }
+  static constexpr int begin_of(int g) {
+    const int lo = PL::rounds[round_of(g)].g0;
+    int b = g;
+    while (b - 1 >= lo && rz1(b - 1)) --b;
+    return b;
+  }
+  static constexpr int len_of(int b) {
+    const int hi = PL::rounds[round_of(b)].g0 + PL::rounds[round_of(b)].ng;
+    int e = b;
+    while (e < hi && rz1(e)) ++e;
+    return e - b;
+  }
+  static constexpr bool fused(int g) { return rz1(g) && len_of(begin_of(g)) >= 2; }
+  static constexpr int ordinal(int b) {   // number of fused runs that begin before gate b
+    int k = 0;
+    for (int g = 0; g < b;) {
+      if (rz1(g)) {
+        const int len = len_of(g);
+        if (len >= 2) ++k;
+        g += len;
+      } else {
+        ++g;
+      }
+    }
+    return k;
+  }
+};
+
 // multiply (x, y) by (-i)^k, k a compile-time constant
 template <int K>
 __device__ __forceinline__ qf2 h2s_rot(const qf2 a) {
@@ -202,10 +245,59 @@ __device__ __forceinline__ void h2s_gate(SV<RB> (&v)[KV], float (&gacc)[NPA], co
   if constexpr (BWD && hg.pidx >= 0) asm volatile("" : "+v"(gacc[hg.pidx]));
 }
 
+// the fused RZ run that begins at gate B0 (see H2sRz)
+template <class PL, int B0, int RB, int KV, bool BWD, int NPA>
+__device__ __forceinline__ void h2s_rz_run(SV<RB> (&v)[KV], float (&gacc)[NPA], const H2Args& A) {
+  constexpr int R = 1 << RB, LEN = H2sRz<PL>::len_of(B0);
+  const auto* P = h2_const(A.rph + H2sRz<PL>::ordinal(B0) * R);
+  if constexpr (BWD) {
+    float t[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+      const qf2 m = v[KV - 1].a[q] * qc_swp(v[0].a[q]);
+      t[q] = m.x - m.y;
+    }
+    h2s_for<0, LEN>([&](auto J) {
+      constexpr H2Gate hg = PL::gates[B0 + J];
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < R; ++q) sum += ((q >> hg.tq) & 1) ? -t[q] : t[q];
+      gacc[hg.pidx] += sum;
+      asm volatile("" : "+v"(gacc[hg.pidx]));   // pinned to this gate (see h2s_gate)
+    });
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const float pr = P[q].re, pi = BWD ? -P[q].im : P[q].im;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) v[k].a[q] = qc_cmul(pr, pi, v[k].a[q]);
+  }
+}
+
+// phase records of the fused RZ runs: out[run][q] = prod_j (c_j -+ i s_j) by bit tq_j of q.  desc per run:
+// {len, gi_0, tq_0, gi_1, tq_1, ...} padded to 1 + 2 * 8 ints
+constexpr int H2S_PH_DESC = 17;
+__global__ void k_h2s_round_phases(const int* __restrict__ desc, int n_runs, int R, const QcTrig* __restrict__ trig,
+                                   Cplx* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_runs * R) return;
+  const int run = i / R, q = i % R;
+  const int* d = desc + run * H2S_PH_DESC;
+  double zr = 1.0, zi = 0.0;
+  for (int j = 0; j < d[0]; ++j) {
+    const QcTrig tr = trig[d[1 + 2 * j]];
+    const double c = tr.c, sg = ((q >> d[2 + 2 * j]) & 1) ? (double)tr.s : -(double)tr.s;   // bit 0: c - i s, bit 1: c + i s
+    const double nr = zr * c - zi * sg, ni = zr * sg + zi * c;
+    zr = nr;
+    zi = ni;
+  }
+  out[i] = {(float)zr, (float)zi};
+}
+
 // MODE 0: forward, MODE 1: backward (chi and lam).  Block = (point, tile of 2^nloc amplitudes), NT = 2^(nloc - RB)
 // threads; mappings (LINEAR / ROUND) as in the interpreter kernel.
 template <class PL, int S, int NCH, int MODE>
-__global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >= 512 ? 4 : (MODE == 1 ? 2 : 4)))
+__global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >= 512 ? 4 : (MODE == 1 ? 2 : 3)))
     k_h2s_stage(const H2Args A) {
   using ST = H2sStage<PL, S>;
   constexpr H2Stage sd = ST::sd;
@@ -425,6 +517,21 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
       H2_SYNC();
     }
   };
+  // backward, last stage: every cotangent lam_c needs the value channel's final amplitudes chi_0 at the thread's own
+  // indices (the same in every channel): read them once, keep them in registers (the channel loop would re-read
+  // the tile five times from HBM)
+  qf2 xz[BWD && LAST ? R : 1];
+  if constexpr (BWD && LAST) {
+    const Cplx* g0 = chi_of(0);
+    if constexpr (din) {
+      using RD0 = H2sRound<PL, S, RF>;
+      const int al0 = abase | h2s_deposit<typename RD0::LaneG, LBITS>(tid);
+      h2s_for<0, R>([&](auto Q) { xz[Q] = *reinterpret_cast<const qf2*>(g0 + RD0::dr(Q) + al0); });
+    } else {
+      const int td0 = abase | h2s_deposit<typename ST::LinG, LBITS>(tid);
+      h2s_for<0, R>([&](auto Q) { xz[Q] = *reinterpret_cast<const qf2*>(g0 + (td0 | ST::lin_dep(Q))); });
+    }
+  }
   struct LinRBP { static constexpr int at(int j) { return H2sStage<PL, S>::LBITS + j; } };
   struct LinLK { static constexpr int at(int k) { return k; } };
 
@@ -452,14 +559,17 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
         });
       } else {
         const Cplx* gl = lam_of(c);
-        const Cplx* g0 = chi_of(0);
         h2s_for<0, R>([&](auto Q) {
           constexpr int q = Q;
           const int a = tdp | ST::lin_dep(q);
-          const qf2 x = *reinterpret_cast<const qf2*>(g + a);
-          qf2 y;
-          if constexpr (LAST) y = build_lam(c, tg | (q << LBITS), x, c == 0 ? x : *reinterpret_cast<const qf2*>(g0 + a), l0acc[q]);
-          else y = *reinterpret_cast<const qf2*>(gl + a);
+          qf2 x, y;
+          if constexpr (LAST) {
+            x = c == 0 ? xz[q] : *reinterpret_cast<const qf2*>(g + a);
+            y = build_lam(c, tg | (q << LBITS), x, xz[q], l0acc[q]);
+          } else {
+            x = *reinterpret_cast<const qf2*>(g + a);
+            y = *reinterpret_cast<const qf2*>(gl + a);
+          }
           *reinterpret_cast<qf2*>(t0 + (tsw ^ ST::lin_sw(q))) = x;
           *reinterpret_cast<qf2*>(t1 + (tsw ^ ST::lin_sw(q))) = y;
         });
@@ -521,15 +631,16 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
             }
           } else {
             const Cplx* gl = lam_of(c);
-            const Cplx* g0 = chi_of(0);
             h2s_for<0, R>([&](auto Q) {
               constexpr int q = Q;
-              const qf2 x = *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
-              qf2 y;
-              if constexpr (LAST)
-                y = build_lam(c, lbase | RD::roff(q), x, c == 0 ? x : *reinterpret_cast<const qf2*>(g0 + RD::dr(q) + alane), l0acc[q]);
-              else
+              qf2 x, y;
+              if constexpr (LAST) {
+                x = c == 0 ? xz[q] : *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
+                y = build_lam(c, lbase | RD::roff(q), x, xz[q], l0acc[q]);
+              } else {
+                x = *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
                 y = *reinterpret_cast<const qf2*>(gl + RD::dr(q) + alane);
+              }
               v[0].a[q] = x;
               v[1].a[q] = y;
             });
@@ -567,7 +678,13 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
 #ifndef H2_ABLATE_GATES
         h2s_for<0, rd.ng>([&](auto GI_) {
           constexpr int gi = rd.g0 + (BWD ? rd.ng - 1 - GI_ : (int)GI_);
-          h2s_gate<PL, gi, RB, KV, BWD, NPA>(v, gacc, A, alane, [](int q) { return RD::dr(q); });
+          if constexpr (H2sRz<PL>::fused(gi)) {
+            // a run of RZ gates on register bits: applied as one phase record where the sweep first meets it
+            constexpr int b0 = H2sRz<PL>::begin_of(gi);
+            if constexpr (gi == (BWD ? b0 + H2sRz<PL>::len_of(b0) - 1 : b0)) h2s_rz_run<PL, b0, RB, KV, BWD, NPA>(v, gacc, A);
+          } else {
+            h2s_gate<PL, gi, RB, KV, BWD, NPA>(v, gacc, A, alane, [](int q) { return RD::dr(q); });
+          }
         });
 #endif
         if constexpr (!BWD && rd.tab_post >= 0) table_here(std::integral_constant<int, rd.tab_post>{}, std::integral_constant<int, rd.ts_post>{});

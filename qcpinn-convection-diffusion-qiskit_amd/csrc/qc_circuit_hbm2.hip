@@ -40,6 +40,8 @@ struct H2Dev {
   std::vector<int> pslot_off;
   int nx = 0, nc = 0;
   const H2sLaunchers* stat = nullptr;   // compile-time stage programs of exactly this plan (gen/qc_static_h2_*.hip), or null
+  int n_ph = 0;                 // fused RZ runs of the compile-time programs (H2sRz), their gate lists on the device
+  int* d_phdesc = nullptr;
 };
 
 // ---------------------------------------------------------------- per-point, per-wire embedding data
@@ -1038,6 +1040,7 @@ struct H2Ws {
   Cplx* store;
   float* wd;
   Cplx* tabs;
+  Cplx* rph;
   float* xpart;
   float* gpart;
   float* dpart;
@@ -1101,6 +1104,31 @@ static int h2s_match(const qc_program* pg, int absorb) {
   return -1;
 }
 
+// fused RZ runs in plan order: the run-time mirror of H2sRz (qc_circuit_h2s_kernels.h); H2S_PH_DESC ints per run
+static std::vector<int> h2s_enumerate_rz_runs(const H2Plan& P) {
+  std::vector<int> desc;
+  auto rz1 = [&](int g) { return P.gates[g].kind == H2_K_REG1 && P.gates[g].op == QC_RZ; };
+  for (const H2Round& r : P.rounds) {
+    if (r.kind != H2_ROUND_GATES) continue;
+    for (int g = r.g0; g < r.g0 + r.ng;) {
+      if (!rz1(g)) { ++g; continue; }
+      int e = g;
+      while (e < r.g0 + r.ng && rz1(e)) ++e;
+      if (e - g >= 2) {
+        std::vector<int> d(H2S_PH_DESC, 0);
+        d[0] = e - g;
+        for (int j = 0; j < e - g && j < 8; ++j) {
+          d[1 + 2 * j] = P.gates[g + j].gi;
+          d[2 + 2 * j] = P.gates[g + j].tq;
+        }
+        desc.insert(desc.end(), d.begin(), d.end());
+      }
+      g = e;
+    }
+  }
+  return desc;
+}
+
 void* qc_h2_create(const qc_program* pg, int absorb) {
   QcH2* h = new QcH2();
   H2Dev& D = h->dev;
@@ -1153,6 +1181,11 @@ void* qc_h2_create(const qc_program* pg, int absorb) {
   up(rank.data(), sizeof(int) * rank.size(), (void**)&D.d_rank);
   up(wht.data(), sizeof(int) * wht.size(), (void**)&D.d_whtidx);
   up(pslots.data(), sizeof(int) * pslots.size(), (void**)&D.d_pslots);
+  if (D.stat) {
+    const std::vector<int> ph = h2s_enumerate_rz_runs(P);
+    D.n_ph = (int)ph.size() / H2S_PH_DESC;
+    up(ph.data(), sizeof(int) * ph.size(), (void**)&D.d_phdesc);
+  }
   if (!ok) {
     qc_h2_destroy(h);
     return nullptr;
@@ -1164,7 +1197,7 @@ void qc_h2_destroy(void* hp) {
   if (!hp) return;
   QcH2* h = (QcH2*)hp;
   H2Dev& D = h->dev;
-  void* ptrs[] = {D.d_rounds, D.d_gates, D.d_dgates, D.d_sparse, D.d_rank, D.d_whtidx, D.d_pslots};
+  void* ptrs[] = {D.d_rounds, D.d_gates, D.d_dgates, D.d_sparse, D.d_rank, D.d_whtidx, D.d_pslots, D.d_phdesc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -1180,7 +1213,7 @@ int qc_h2_describe_gates(const QcGate* gates, int n_gates, int n_qubits, int abs
 // bytes that do not depend on the number of resident tiles, and bytes per resident 64-point tile
 static size_t h2_fixed_bytes(const qc_program* pg, const H2Dev& D) {
   const size_t N = (size_t)1 << pg->n_qubits;
-  return al(sizeof(Cplx) * D.plan.tables.size() * N + 256);
+  return al(sizeof(Cplx) * D.plan.tables.size() * N + 256) + al(sizeof(Cplx) * ((size_t)D.n_ph << D.plan.rbits) + 256);
 }
 static size_t h2_tile_bytes(const qc_program* pg, const H2Dev& D, int nch, bool backward) {
   const size_t N = (size_t)1 << pg->n_qubits;
@@ -1214,6 +1247,7 @@ static H2Ws h2_carve(const qc_program* pg, const H2Dev& D, int nch, bool backwar
   char* p = (char*)ws;
   H2Ws w = {};
   w.tabs = (Cplx*)p; p += al(sizeof(Cplx) * D.plan.tables.size() * N + 256);
+  w.rph = (Cplx*)p; p += al(sizeof(Cplx) * ((size_t)D.n_ph << D.plan.rbits) + 256);
   w.wd = (float*)p; p += (size_t)G * al(sizeof(float) * 64 * pg->n_qubits * 8);
   w.store = (Cplx*)p; p += (size_t)G * al(sizeof(Cplx) * (backward ? 2 : 1) * nch * 64 * N);
   w.xpart = (float*)p; p += (size_t)G * al(sizeof(float) * 8 * 64 * ntau * H2_XW);
@@ -1285,6 +1319,7 @@ static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, c
   A.trig = trig;
   A.umat = umat;
   A.tabs = w.tabs;
+  A.rph = w.rph;
   A.wd = w.wd;
   A.xpart = w.xpart;
   A.qbar = qbar;
@@ -1368,6 +1403,9 @@ static int h2_run(const qc_program* pg, void* hp, const QcTrig* trig, const floa
       hipLaunchKernelGGL(k_h2_diag_table, dim3(qc_ceil_div((int64_t)N, 256)), dim3(256), 0, st, D.d_dgates + D.plan.tables[k].g0,
                          D.plan.tables[k].ng, trig, n, w.tabs + k * N);
   }
+  if (!resident && D.stat && D.n_ph > 0)
+    hipLaunchKernelGGL(k_h2s_round_phases, dim3(qc_ceil_div((int64_t)D.n_ph << D.plan.rbits, 64)), dim3(64), 0, st, D.d_phdesc, D.n_ph,
+                       1 << D.plan.rbits, trig, w.rph);
   for (int64_t t0 = 0; t0 < ntiles; t0 += G) {
     const int64_t p_first = t0 * 64;
     const int64_t npts = (B - p_first) < G * 64 ? (B - p_first) : G * 64;

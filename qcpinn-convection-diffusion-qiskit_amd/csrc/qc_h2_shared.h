@@ -55,6 +55,7 @@ struct H2Args {
   const QcTrig* trig;
   const float* umat;
   const Cplx* tabs;      // [n_tables][2^n]
+  const Cplx* rph;       // compile-time stage programs: phase records of the fused RZ runs, [n_runs][2^RB]
   const float* wd;       // [pt_stride][n][8]
   float* xpart;          // forward, last stage: [8][pt_stride][ntau][H2_XW]
   const float* qbar;     // backward, last stage: [nch][n][B]

@@ -126,6 +126,18 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
       if (share) pred[j].push_back(i);
     }
   }
+  // candidate order of the non-diagonal gates: by the highest bit that must be tile-local, then by program position
+  std::vector<int> low_first(G);
+  {
+    auto key = [&](int j) {
+      const QcGate& g = gate(j);
+      if (g.op == QC_U4) return g.ba > g.bb ? g.ba : g.bb;
+      if (g.op == QC_CNOT || g.op == QC_CRX) return g.bb;
+      return g.ba;
+    };
+    for (int j = 0; j < G; ++j) low_first[j] = j;
+    std::stable_sort(low_first.begin(), low_first.end(), [&](int a, int b) { return key(a) < key(b); });
+  }
   std::vector<int> state(G, 0);   // 0 = waiting, 1 = in the current stage, 2 = done
   int n_done = 0;
   while (n_done < G) {
@@ -172,11 +184,14 @@ inline H2Plan h2_make_plan(const QcGate* gates, int n_gates, int n, int absorb, 
           progress = true;
         }
       }
-      // (2) non-diagonal gates, program order, repeated until nothing more fits
+      // (2) non-diagonal gates, LOW target bits first (then program order), repeated until nothing more fits: the
+      // stage that runs most of a layer then owns the low index bits (a tile = one contiguous run of HBM), and the
+      // bits left to the next stage are high ones - its register bits - so that its lanes, too, walk contiguous memory
       bool any = true;
       while (any) {
         any = false;
-        for (int j = 0; j < G; ++j) {
+        for (int jj = 0; jj < G; ++jj) {
+          const int j = low_first[jj];
           if (h2_is_diag(gate(j).op) || !ready(j)) continue;
           // bits that must be local: the target (a control may sit anywhere), both bits of a two-wire unitary
           int b[2];

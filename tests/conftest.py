@@ -27,3 +27,34 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no GPU is visible (these tests never fall back to CPU)")
     return torch.device("cuda", 0)
+
+
+# ---- committed outputs of the float64 CPU oracle for the seeded inputs of the slow parity cases
+ORACLE_CACHE = os.path.join(GOLDEN, "oracle")
+
+
+def cached_oracle(key: str, inputs, compute):
+    """Outputs of the CPU oracle for one parity case: ``compute()`` -> dict of numpy arrays.
+
+    The float64 statevector oracle costs up to a minute per case on the GPU box's CPU; its outputs for the seeded
+    inputs of the tests are committed under tests/golden/oracle/ (generated in the build container by
+    tests/golden/make_oracle_cache.py, which calls the same test-module functions).  A record is used only if the
+    checksum of the inputs it was computed for matches the inputs of this run; otherwise (or when no record exists) the
+    oracle runs here.  QC_WRITE_ORACLE_CACHE=1 writes / refreshes records."""
+    import hashlib
+
+    import numpy as np
+    h = hashlib.sha256()
+    for a in inputs:
+        h.update(np.ascontiguousarray(np.asarray(a)).tobytes())
+    digest = np.frombuffer(h.digest()[:8], dtype=np.int64).copy()
+    path = os.path.join(ORACLE_CACHE, key + ".npz")
+    if os.path.exists(path) and os.environ.get("QC_WRITE_ORACLE_CACHE") != "1":
+        z = np.load(path)
+        if "inputs_digest" in z.files and int(z["inputs_digest"][0]) == int(digest[0]):
+            return {k: z[k] for k in z.files if k != "inputs_digest"}
+    out = {k: np.asarray(v) for k, v in compute().items()}
+    if os.environ.get("QC_WRITE_ORACLE_CACHE") == "1":
+        os.makedirs(ORACLE_CACHE, exist_ok=True)
+        np.savez_compressed(path, inputs_digest=digest, **out)
+    return out

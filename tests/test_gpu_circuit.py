@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, pkg
+from conftest import GOLDEN, cached_oracle, pkg
 
 from oracle import jets as ojets
 from oracle import statevector as sv
@@ -24,6 +24,50 @@ def _circuit(ans, n, L, seed, device):
     prog = circuits.build_program(ans, n, L, use_haar)
     haar = circuits.haar_unitaries(seed, seed + 1) if use_haar else None
     return engine.Circuit(prog, haar, device), (sv.haar_pair(seed, seed + 1) if use_haar else None)
+
+
+# ---- seeded inputs and float64 oracle outputs of the parity cases (the oracle part is cached: conftest.cached_oracle;
+# tests/golden/make_oracle_cache.py calls these same functions in the build container)
+def vjp_inputs(ans, n, L, B, salt):
+    g = torch.Generator().manual_seed(salt + n + B)
+    P = pkg("circuits").params_per_layer(ans, n)
+    params = torch.randn(L, P, generator=g) * 0.8
+    x = torch.randn(B, n, generator=g) * 1.1
+    cot = torch.randn(n, B, generator=g)
+    return params, x, cot
+
+
+def vjp_oracle(ans, n, L, seed, B, params, x, cot, encoding="angle", tag="vjp"):
+    haar = sv.haar_pair(seed, seed + 1) if (seed is not None and n >= 4) else None
+
+    def compute():
+        xo = x.double().requires_grad_(True)
+        po = params.double().requires_grad_(True)
+        q = sv.circuit_expvals(xo, po, ans, n, haar) if encoding == "angle" else sv.circuit_expvals(xo, po, ans, n, haar, encoding)
+        (q * cot.double()).sum().backward()
+        return {"q": q.detach().numpy(), "dx": xo.grad.numpy(), "dp": po.grad.numpy()}
+    return cached_oracle(f"{tag}_{ans}_n{n}_L{L}_s{seed}_B{B}", (params.numpy(), x.numpy(), cot.numpy()), compute)
+
+
+def jets_inputs(ans, n, L, B, salt=77):
+    g = torch.Generator().manual_seed(salt + n + B)
+    P = pkg("circuits").params_per_layer(ans, n)
+    params = torch.randn(L, P, generator=g) * 0.8
+    ajets = torch.randn(6, n, B, generator=g) * 0.9
+    w = torch.randn(6, n, B, generator=g)
+    return params, ajets, w
+
+
+def jets_oracle(ans, n, L, seed, B, params, ajets, w, encoding="angle", tag="jets"):
+    haar = sv.haar_pair(seed, seed + 1) if (seed is not None and n >= 4) else None
+
+    def compute():
+        ao = ajets.double().requires_grad_(True)
+        po = params.double().requires_grad_(True)
+        qo = ojets.qjets_from_ajets(ao, po, ans, n, haar) if encoding == "angle" else ojets.qjets_from_ajets(ao, po, ans, n, haar, encoding)
+        (qo * w.double()).sum().backward()
+        return {"q": qo.detach().numpy(), "da": ao.grad.numpy(), "dp": po.grad.numpy()}
+    return cached_oracle(f"{tag}_{ans}_n{n}_L{L}_s{seed}_B{B}", (params.numpy(), ajets.numpy(), w.numpy()), compute)
 
 
 def _golden_cases(max_n):
@@ -55,69 +99,59 @@ def test_expval_matches_golden(fname, gpu_device):
     assert np.abs(q - z["expval"]).max() < TOL_Z
 
 
-@pytest.mark.parametrize("ans,n,L,seed,B", [
+VJP_CASES = [
     ("cascade", 4, 1, 1, 200), ("layered", 4, 2, 1, 70), ("cross_mesh", 4, 1, 1, 65), ("farhi", 4, 1, 1, 64),
     ("sim_circ_15", 4, 1, 1, 33), ("alternate", 5, 1, 1, 40), ("cascade", 3, 2, None, 50), ("cascade", 2, 1, None, 10),
     ("cascade", 5, 1, 1, 129), ("cascade", 4, 1, None, 300),
     ("cascade", 6, 1, 1, 70), ("layered", 7, 1, 1, 20), ("layered", 8, 2, 1, 37), ("cross_mesh", 8, 1, 1, 5),
     ("farhi", 6, 1, 1, 18), ("cascade", 9, 1, 1, 70), ("layered", 10, 1, 1, 5), ("cross_mesh", 16, 1, 1, 2),
-])
+]
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", VJP_CASES)
 def test_expval_vjp_matches_oracle_autograd(ans, n, L, seed, B, gpu_device):
     """Backward of DVQuantumLayer: d/d(angles) and d/d(theta) of sum(cot * <Z>)."""
-    g = torch.Generator().manual_seed(5 + n + B)
-    circuits = pkg("circuits")
-    P = circuits.params_per_layer(ans, n)
-    params = (torch.randn(L, P, generator=g) * 0.8)
-    x = torch.randn(B, n, generator=g) * 1.1
-    cot = torch.randn(n, B, generator=g)
+    params, x, cot = vjp_inputs(ans, n, L, B, 5)
     circ, haar = _circuit(ans, n, L, seed, gpu_device)
-    # oracle
-    xo = x.double().requires_grad_(True)
-    po = params.double().requires_grad_(True)
-    q = sv.circuit_expvals(xo, po, ans, n, haar)
-    (q * cot.double()).sum().backward()
+    o = vjp_oracle(ans, n, L, seed, B, params, x, cot)
     # HIP
     circ.prepare(params.to(gpu_device))
     ang = x.t().contiguous().to(gpu_device)
     qh = circ.forward_expval(ang)
-    assert (qh.cpu().double() - q.detach()).abs().max() < TOL_Z
+    assert np.abs(qh.cpu().double().numpy() - o["q"]).max() < TOL_Z
     d_ang, d_theta = circ.backward_expval(ang, cot.to(gpu_device))
-    assert (d_ang.t().cpu().double() - xo.grad).abs().max() < 2e-5
-    scale = max(1.0, po.grad.abs().max().item())
-    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 1e-5 * scale * np.sqrt(B)
+    assert np.abs(d_ang.t().cpu().double().numpy() - o["dx"]).max() < 2e-5
+    scale = max(1.0, np.abs(o["dp"]).max())
+    assert np.abs(d_theta.cpu().double().numpy() - o["dp"].reshape(-1)).max() < 1e-5 * scale * np.sqrt(B)
 
 
-@pytest.mark.parametrize("ans,n,L,seed,B", [
+JETS_CASES = [
     ("cascade", 4, 1, 1, 70), ("layered", 4, 1, 1, 9), ("cross_mesh", 4, 1, 1, 6), ("cascade", 3, 1, None, 8),
     ("cascade", 2, 1, None, 5), ("alternate", 5, 1, 1, 5),
     ("cascade", 6, 1, 1, 3), ("layered", 7, 1, 1, 2), ("layered", 8, 1, 1, 1), ("sim_circ_15", 6, 1, 1, 2),
     ("cascade", 7, 1, 1, 1),   # no generated static program: the run-time interpreter of the wave family
-    ("cascade", 9, 1, 1, 1),   # (8-qubit x2 layers and n = 10 are covered by the training fixture / the value tests:
-])                             #  the float64 oracle's jets cost ~1 min per case there)
+    ("cascade", 9, 1, 1, 1),
+    ("layered", 8, 2, 1, 3), ("layered", 10, 1, 1, 2),   # (the float64 oracle's jets cost ~1 min per case: cached)
+]
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", JETS_CASES)
 def test_jets_forward_and_vjp_match_oracle(ans, n, L, seed, B, gpu_device):
     """Six derivative channels through the circuit and their cotangents (angle jets + theta)."""
-    g = torch.Generator().manual_seed(77 + n + B)
-    circuits = pkg("circuits")
-    P = circuits.params_per_layer(ans, n)
-    params = torch.randn(L, P, generator=g) * 0.8
-    ajets = torch.randn(6, n, B, generator=g) * 0.9
-    w = torch.randn(6, n, B, generator=g)
+    params, ajets, w = jets_inputs(ans, n, L, B)
     circ, haar = _circuit(ans, n, L, seed, gpu_device)
-    ao = ajets.double().requires_grad_(True)
-    po = params.double().requires_grad_(True)
-    qo = ojets.qjets_from_ajets(ao, po, ans, n, haar)
-    (qo * w.double()).sum().backward()
+    o = jets_oracle(ans, n, L, seed, B, params, ajets, w)
     circ.prepare(params.to(gpu_device))
     aj = ajets.to(gpu_device)
     qh = circ.forward_jets(aj)
-    err = (qh.cpu().double() - qo.detach()).abs()
+    err = np.abs(qh.cpu().double().numpy() - o["q"])
     assert err[0].max() < TOL_Z
-    assert err.max() < 1e-5 * max(1.0, qo.detach().abs().max().item())
+    assert err.max() < 1e-5 * max(1.0, np.abs(o["q"]).max())
     abar, d_theta = circ.backward_jets(aj, w.to(gpu_device))
-    sa = max(1.0, ao.grad.abs().max().item())
-    assert (abar.cpu().double() - ao.grad).abs().max() < 2e-5 * sa
-    st = max(1.0, po.grad.abs().max().item())
-    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 2e-5 * st
+    sa = max(1.0, np.abs(o["da"]).max())
+    assert np.abs(abar.cpu().double().numpy() - o["da"]).max() < 2e-5 * sa
+    st = max(1.0, np.abs(o["dp"]).max())
+    assert np.abs(d_theta.cpu().double().numpy() - o["dp"].reshape(-1)).max() < 2e-5 * st
 
 
 def test_wave_family_agrees_with_oracle_at_small_n():
@@ -151,45 +185,46 @@ def test_hbm_per_gate_path_agrees_with_staged_path():
     assert "4 passed" in r.stdout
 
 
-@pytest.mark.parametrize("ans,n,L,seed,B", [("cascade", 4, 1, 1, 70), ("layered", 5, 1, 1, 9), ("layered", 6, 1, 1, 5),
-                                              ("layered", 8, 1, 1, 2), ("cascade", 9, 1, 1, 2), ("cascade", 2, 1, None, 6)])
-def test_amplitude_encoding_matches_oracle(ans, n, L, seed, B, gpu_device):
-    """encoding="amplitude" (AmplitudeEmbedding, nn/DVQuantumLayer.py:177-180): <Z>, its vjp, the six
-    derivative channels and their cotangents, in all three kernel families."""
+AMP_CASES = [("cascade", 4, 1, 1, 70), ("layered", 5, 1, 1, 9), ("layered", 6, 1, 1, 5),
+             ("layered", 8, 1, 1, 2), ("cascade", 9, 1, 1, 2), ("cascade", 2, 1, None, 6)]
+
+
+def amp_inputs(ans, n, L, B):
     g = torch.Generator().manual_seed(31 + n + B)
-    circuits = pkg("circuits")
-    engine = pkg("hip.engine")
-    P = circuits.params_per_layer(ans, n)
-    use_haar = seed is not None and n >= 4
-    prog = circuits.build_program(ans, n, L, use_haar)
-    haar_np = circuits.haar_unitaries(seed, seed + 1) if use_haar else None
-    haar = sv.haar_pair(seed, seed + 1) if use_haar else None
-    circ = engine.Circuit(prog, haar_np, gpu_device, amplitude=True)
+    P = pkg("circuits").params_per_layer(ans, n)
     params = torch.randn(L, P, generator=g) * 0.8
     x = torch.randn(B, n, generator=g) + 0.3
     cot = torch.randn(n, B, generator=g)
-    xo = x.double().requires_grad_(True)
-    po = params.double().requires_grad_(True)
-    q = sv.circuit_expvals(xo, po, ans, n, haar, "amplitude")
-    (q * cot.double()).sum().backward()
-    circ.prepare(params.to(gpu_device))
-    ang = x.t().contiguous().to(gpu_device)
-    qh = circ.forward_expval(ang)
-    assert (qh.cpu().double() - q.detach()).abs().max() < TOL_Z
-    d_ang, d_theta = circ.backward_expval(ang, cot.to(gpu_device))
-    assert (d_ang.t().cpu().double() - xo.grad).abs().max() < 2e-5 * max(1.0, xo.grad.abs().max().item())
-    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 2e-5 * max(1.0, po.grad.abs().max().item()) * np.sqrt(B)
-    # derivative channels
     ajets = torch.randn(6, n, B, generator=g) * 0.9
     ajets[0] += 0.3
     w = torch.randn(6, n, B, generator=g)
-    ao = ajets.double().requires_grad_(True)
-    po2 = params.double().requires_grad_(True)
-    qo = ojets.qjets_from_ajets(ao, po2, ans, n, haar, "amplitude")
-    (qo * w.double()).sum().backward()
+    return params, x, cot, ajets, w
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", AMP_CASES)
+def test_amplitude_encoding_matches_oracle(ans, n, L, seed, B, gpu_device):
+    """encoding="amplitude" (AmplitudeEmbedding, nn/DVQuantumLayer.py:177-180): <Z>, its vjp, the six
+    derivative channels and their cotangents, in all three kernel families."""
+    circuits = pkg("circuits")
+    engine = pkg("hip.engine")
+    use_haar = seed is not None and n >= 4
+    prog = circuits.build_program(ans, n, L, use_haar)
+    haar_np = circuits.haar_unitaries(seed, seed + 1) if use_haar else None
+    circ = engine.Circuit(prog, haar_np, gpu_device, amplitude=True)
+    params, x, cot, ajets, w = amp_inputs(ans, n, L, B)
+    o = vjp_oracle(ans, n, L, seed, B, params, x, cot, "amplitude", "ampvjp")
+    circ.prepare(params.to(gpu_device))
+    ang = x.t().contiguous().to(gpu_device)
+    qh = circ.forward_expval(ang)
+    assert np.abs(qh.cpu().double().numpy() - o["q"]).max() < TOL_Z
+    d_ang, d_theta = circ.backward_expval(ang, cot.to(gpu_device))
+    assert np.abs(d_ang.t().cpu().double().numpy() - o["dx"]).max() < 2e-5 * max(1.0, np.abs(o["dx"]).max())
+    assert np.abs(d_theta.cpu().double().numpy() - o["dp"].reshape(-1)).max() < 2e-5 * max(1.0, np.abs(o["dp"]).max()) * np.sqrt(B)
+    # derivative channels
+    oj = jets_oracle(ans, n, L, seed, B, params, ajets, w, "amplitude", "ampjets")
     aj = ajets.to(gpu_device)
     qj = circ.forward_jets(aj)
-    assert (qj.cpu().double() - qo.detach()).abs().max() < 2e-5 * max(1.0, qo.detach().abs().max().item())
+    assert np.abs(qj.cpu().double().numpy() - oj["q"]).max() < 2e-5 * max(1.0, np.abs(oj["q"]).max())
     abar, d_theta = circ.backward_jets(aj, w.to(gpu_device))
-    assert (abar.cpu().double() - ao.grad).abs().max() < 5e-5 * max(1.0, ao.grad.abs().max().item())
-    assert (d_theta.cpu().double() - po2.grad.reshape(-1)).abs().max() < 5e-5 * max(1.0, po2.grad.abs().max().item())
+    assert np.abs(abar.cpu().double().numpy() - oj["da"]).max() < 5e-5 * max(1.0, np.abs(oj["da"]).max())
+    assert np.abs(d_theta.cpu().double().numpy() - oj["dp"].reshape(-1)).max() < 5e-5 * max(1.0, np.abs(oj["dp"]).max())

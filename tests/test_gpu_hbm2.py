@@ -12,38 +12,30 @@ import pytest
 import torch
 
 from conftest import pkg
-from test_gpu_circuit import TOL_Z, _circuit
+from test_gpu_circuit import TOL_Z, _circuit, jets_inputs, jets_oracle, vjp_inputs, vjp_oracle
 
 from oracle import jets as ojets
 from oracle import statevector as sv
 
 pytestmark = pytest.mark.gpu
 
-VJP_CASES = [("cross_mesh", 12, 1, 1, 70), ("cascade", 14, 1, 1, 66), ("layered", 13, 1, 1, 3), ("sim_circ_15", 11, 1, 1, 5),
+VJP_CASES = [("cross_mesh", 12, 1, 1, 70), ("cross_mesh", 13, 1, 1, 3), ("cascade", 14, 1, 1, 66), ("layered", 13, 1, 1, 3), ("sim_circ_15", 11, 1, 1, 5),
              ("farhi", 10, 1, 1, 9), ("alternate", 9, 1, 1, 130), ("layered", 12, 2, 1, 2), ("cross_mesh", 9, 1, 1, 65)]
 
 
 @pytest.mark.parametrize("ans,n,L,seed,B", VJP_CASES)
 def test_value_channel_and_vjp_match_oracle(ans, n, L, seed, B, gpu_device):
-    g = torch.Generator().manual_seed(11 + n + B)
-    circuits = pkg("circuits")
-    P = circuits.params_per_layer(ans, n)
-    params = torch.randn(L, P, generator=g) * 0.8
-    x = torch.randn(B, n, generator=g) * 1.1
-    cot = torch.randn(n, B, generator=g)
+    params, x, cot = vjp_inputs(ans, n, L, B, 11)
     circ, haar = _circuit(ans, n, L, seed, gpu_device)
-    xo = x.double().requires_grad_(True)
-    po = params.double().requires_grad_(True)
-    q = sv.circuit_expvals(xo, po, ans, n, haar)
-    (q * cot.double()).sum().backward()
+    o = vjp_oracle(ans, n, L, seed, B, params, x, cot, tag="h2vjp")
     circ.prepare(params.to(gpu_device))
     ang = x.t().contiguous().to(gpu_device)
     qh = circ.forward_expval(ang)
-    assert (qh.cpu().double() - q.detach()).abs().max() < TOL_Z
+    assert np.abs(qh.cpu().double().numpy() - o["q"]).max() < TOL_Z
     d_ang, d_theta = circ.backward_expval(ang, cot.to(gpu_device))
-    assert (d_ang.t().cpu().double() - xo.grad).abs().max() < 2e-5
-    scale = max(1.0, po.grad.abs().max().item())
-    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 1e-5 * scale * np.sqrt(B)
+    assert np.abs(d_ang.t().cpu().double().numpy() - o["dx"]).max() < 2e-5
+    scale = max(1.0, np.abs(o["dp"]).max())
+    assert np.abs(d_theta.cpu().double().numpy() - o["dp"].reshape(-1)).max() < 1e-5 * scale * np.sqrt(B)
     # a workspace that holds ONE tile: the same batch in ceil(B / 64) launches, forward recomputed in the adjoint pass
     lib = circ.lib
     one = int(lib.qc_circuit_workspace_bytes(circ.handle, 1, 1))
@@ -57,33 +49,29 @@ def test_value_channel_and_vjp_match_oracle(ans, n, L, seed, B, gpu_device):
                                     ang.data_ptr(), cot.to(gpu_device).data_ptr(), d2.data_ptr(), part.data_ptr(),
                                     part.shape[1], 0, B, ws.data_ptr(), one, st))
     assert torch.equal(d2, d_ang)                              # same kernels, same order: bit-identical
-    assert (part.sum(0)[: circ.n_params].cpu().double() - po.grad.reshape(-1)).abs().max() < 1e-5 * scale * np.sqrt(B)
+    assert np.abs(part.sum(0)[: circ.n_params].cpu().double().numpy() - o["dp"].reshape(-1)).max() < 1e-5 * scale * np.sqrt(B)
 
 
-@pytest.mark.parametrize("ans,n,L,seed,B", [("cross_mesh", 10, 1, 1, 2), ("cascade", 11, 1, 1, 1), ("layered", 9, 2, 1, 2)])
+SIX_CASES = [("cross_mesh", 10, 1, 1, 2), ("cascade", 11, 1, 1, 1), ("layered", 9, 2, 1, 2),
+             ("cross_mesh", 12, 1, 1, 2), ("cross_mesh", 13, 1, 1, 1)]   # 12 and 13: compile-time stage programs, one and two stages
+
+
+@pytest.mark.parametrize("ans,n,L,seed,B", SIX_CASES)
 def test_six_channels_and_cotangents_match_oracle(ans, n, L, seed, B, gpu_device):
-    g = torch.Generator().manual_seed(77 + n + B)
-    circuits = pkg("circuits")
-    P = circuits.params_per_layer(ans, n)
-    params = torch.randn(L, P, generator=g) * 0.8
-    ajets = torch.randn(6, n, B, generator=g) * 0.9
-    w = torch.randn(6, n, B, generator=g)
+    params, ajets, w = jets_inputs(ans, n, L, B)
     circ, haar = _circuit(ans, n, L, seed, gpu_device)
-    ao = ajets.double().requires_grad_(True)
-    po = params.double().requires_grad_(True)
-    qo = ojets.qjets_from_ajets(ao, po, ans, n, haar)
-    (qo * w.double()).sum().backward()
+    o = jets_oracle(ans, n, L, seed, B, params, ajets, w, tag="h2jets")
     circ.prepare(params.to(gpu_device))
     aj = ajets.to(gpu_device)
     qh = circ.forward_jets(aj)
-    err = (qh.cpu().double() - qo.detach()).abs()
+    err = np.abs(qh.cpu().double().numpy() - o["q"])
     assert err[0].max() < TOL_Z
-    assert err.max() < 1e-5 * max(1.0, qo.detach().abs().max().item())
+    assert err.max() < 1e-5 * max(1.0, np.abs(o["q"]).max())
     abar, d_theta = circ.backward_jets(aj, w.to(gpu_device))
-    sa = max(1.0, ao.grad.abs().max().item())
-    assert (abar.cpu().double() - ao.grad).abs().max() < 2e-5 * sa
-    st = max(1.0, po.grad.abs().max().item())
-    assert (d_theta.cpu().double() - po.grad.reshape(-1)).abs().max() < 2e-5 * st
+    sa = max(1.0, np.abs(o["da"]).max())
+    assert np.abs(abar.cpu().double().numpy() - o["da"]).max() < 2e-5 * sa
+    st = max(1.0, np.abs(o["dp"]).max())
+    assert np.abs(d_theta.cpu().double().numpy() - o["dp"].reshape(-1)).max() < 2e-5 * st
 
 
 @pytest.mark.parametrize("env", [{"QC_H2_RB": "4"}, {"QC_HBM_V1": "1"}, {"QC_NO_ABSORB": "1"}])
