@@ -25,9 +25,11 @@ namespace {
 
 // tanh(x) = 1 - 2/(exp(2x)+1) on the hardware exp/rcp units (abs. error ~1e-7; saturates cleanly
 // to +-1 for |x| large, where exp overflows to inf or underflows to 0).
+// (__frcp_rn is a correctly rounded division on this target: ten instructions with v_div_scale / v_div_fmas / v_div_fixup;
+// the hardware reciprocal is 1 ulp, far inside the 1e-7 of the exp approximation.)
 __device__ __forceinline__ float qc_tanh(float x) {
   const float e = __expf(2.f * x);
-  return 1.f - 2.f * __frcp_rn(e + 1.f);
+  return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
 // analytic solution and forcing term, data/diffusion_dataset.py:20-38
