@@ -726,6 +726,215 @@ __device__ __forceinline__ void k_post_value4(const int64_t bid, const float* __
   }
 }
 
+// ================================================================== post stage of the training step in ONE kernel
+// (MODE 2 of k_post + k_post_wg).  lane = collocation point throughout, weights are scalar operands:
+//   phase A  u jets of the tile (pre-activations, tanh once per (point, hidden unit); the tanh values of a residual tile
+//            are parked in LDS), residual, analytic target, squared error -> the point's cotangent (gsc or ub0);
+//   phase B  with the ACTUAL cotangent: cotangents of the pre-activations gb_c, the <Z> jet cotangents
+//            qbar_c[i] += W3[m][i] gb_c, and the weight gradients in the same lanes: the per-point products
+//            sum_c gb_c q_c[i] (W3), gb_0 (b3), gw4 (W4) are summed over the wave's 64 points by DPP reductions and
+//            stored straight into the tile's partial row - one row entry has exactly one producing wave.
+// The lane = hidden-unit kernel (k_post_wg) recomputed pre-activations, tanh and cotangents per (hidden unit, point)
+// from LDS copies of the jets: ~130 wave-instructions per (point, 64 hidden lanes) for what costs 24 multiply-adds and
+// a few reductions here.  WPT = waves per tile: 4 (residual tiles: hidden units split four ways, partial sums meet in
+// LDS) or 1 (value tiles: one wave owns the tile, four tiles per block).
+template <int N, int NCH, int WPT>
+__device__ __forceinline__ void k_post_fused_body(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm,
+                                                   QcLayout L, QcPde pde, const float* __restrict__ qjets,
+                                                   float* __restrict__ out_u, float* __restrict__ out_res,
+                                                   float* __restrict__ qbar, float* __restrict__ part, int64_t part_stride,
+                                                   int64_t row0, int64_t B, float* __restrict__ s_z) {
+  __shared__ float s_buf[WPT == 4 ? QC_MS : 1][WPT == 4 ? NCH * N : 1][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = WPT == 4 ? bid : bid * 4 + wave;
+  if (WPT == 1 && tile * 64 >= B) return;
+  const int64_t p = tile * 64 + lane;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+  float q[NCH][N];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[c][i] = qjets[((int64_t)c * N + i) * B + pc];
+  const float* W3 = prm + L.oW3;
+  const float* b3 = prm + L.ob3;
+  const float* W4 = prm + L.oW4;
+  const int hq = (L.H + QC_MS - 1) / QC_MS;
+  const int m0 = WPT == 4 ? wave * hq : 0, m1 = WPT == 4 ? ((m0 + hq) < L.H ? (m0 + hq) : L.H) : L.H;
+  // ---------------- phase A
+  float u[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) u[c] = 0.f;
+  if constexpr (WPT == 4) {
+    for (int m = m0; m < m1; ++m) {
+      float g[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float sum = (c == 0) ? b3[m] : 0.f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) sum = fmaf(W3[m * N + i], q[c][i], sum);
+        g[c] = sum;
+      }
+      const float z = qc_tanh(g[0]);
+      s_z[m * 64 + lane] = z;
+      const float w4 = W4[m];
+      u[0] = fmaf(w4, z, u[0]);
+      if constexpr (NCH == 6) {
+        const float d1 = 1.f - z * z, d2 = -2.f * z * d1;
+        u[1] = fmaf(w4, d1 * g[1], u[1]);
+        u[2] = fmaf(w4, d1 * g[2], u[2]);
+        u[3] = fmaf(w4, d1 * g[3], u[3]);
+        u[4] = fmaf(w4, d2 * g[2] * g[2] + d1 * g[4], u[4]);
+        u[5] = fmaf(w4, d2 * g[3] * g[3] + d1 * g[5], u[5]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) s_buf[wave][c][lane] = u[c];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      u[c] = (s_buf[0][c][lane] + s_buf[1][c][lane]) + (s_buf[2][c][lane] + s_buf[3][c][lane]);
+    __syncthreads();   // s_buf is reused for the qbar partials below
+  } else {
+    // one wave, all hidden units; the four quarter sums are formed and added as in the four-wave form
+    float up[QC_MS];
+#pragma unroll
+    for (int k = 0; k < QC_MS; ++k) {
+      up[k] = 0.f;
+      const int k0 = k * hq, k1 = (k0 + hq) < L.H ? (k0 + hq) : L.H;
+      for (int m = k0; m < k1; ++m) {
+        float g = b3[m];
+#pragma unroll
+        for (int i = 0; i < N; ++i) g = fmaf(W3[m * N + i], q[0][i], g);
+        up[k] = fmaf(W4[m], qc_tanh(g), up[k]);
+      }
+    }
+    u[0] = (up[0] + up[1]) + (up[2] + up[3]);
+  }
+  u[0] += prm[L.ob4];
+  // ---------------- residual / error / loss sums / per-point cotangent
+  const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
+  float* row = part + (row0 + tile) * part_stride;
+  float ub0 = 0.f, gsc = 0.f;
+  if constexpr (NCH == 6) {
+    const float res = pde.c_t * u[1] + pde.c_x * u[2] + pde.c_y * u[3] - (pde.d_xx * u[4] + pde.d_yy * u[5]);
+    const float target = pde.problem == QC_PB_PURE_DIFFUSION ? 0.f : analytic_r(t, x, y, pde.D, pde.vx, pde.vy);
+    const float e = live ? res - target : 0.f;
+    gsc = pde.w_res * e;
+    if (wave == 0 || WPT == 1) {
+      const float ls = qc_wave_sum_to_lane63(e * e * pde.inv_n_res);
+      if (lane == 63) {
+        row[L.NP + 0] = ls;
+        row[L.NP + 1] = 0.f;
+        row[L.NP + 2] = 0.f;
+      }
+    }
+  } else {
+    const bool seg_a = p < pde.n_seg_a;
+    const float target = pde.problem == QC_PB_PURE_DIFFUSION ? (seg_a ? analytic_u_diffusion(t, x, y, pde.D) : 0.f)
+                                                             : analytic_u(t, x, y);
+    const float e = live ? u[0] - target : 0.f;
+    ub0 = (seg_a ? pde.w_val_a : pde.w_val_b) * e;
+    if (wave == 0 || WPT == 1) {
+      const float la = qc_wave_sum_to_lane63(seg_a ? e * e * pde.inv_n_a : 0.f);
+      const float lb = qc_wave_sum_to_lane63(seg_a ? 0.f : e * e * pde.inv_n_b);
+      if (lane == 63) {
+        row[L.NP + 0] = 0.f;
+        row[L.NP + 1] = lb;  // column order: residual, BC, IC; segment a = IC, b = BC
+        row[L.NP + 2] = la;
+      }
+    }
+  }
+  if (live && (wave == 0 || WPT == 1)) {   // the per-point cotangents (MODE 2 contract of qc_post)
+    out_u[p] = ub0;
+    if constexpr (NCH == 6) out_res[p] = gsc;
+  }
+  // d loss / d b4 = sum of the points' cotangents of u (zero for residual tiles: the loss sees u only through the residual)
+  if (wave == 0 || WPT == 1) {
+    const float sb4 = qc_wave_sum_to_lane63(ub0);
+    if (lane == 63) row[L.ob4] = sb4;
+  }
+  // ---------------- phase B
+  float ub[NCH];
+  expand_ub<NCH>(ub, ub0, gsc, pde);
+  float qb[NCH][N];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) qb[c][i] = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    float g[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (WPT == 4 && c == 0) {   // only tanh(g_0) is needed, and that is parked
+        g[0] = 0.f;
+        continue;
+      }
+      float sum = (c == 0) ? b3[m] : 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sum = fmaf(W3[m * N + i], q[c][i], sum);
+      g[c] = sum;
+    }
+    const float z = WPT == 4 ? s_z[m * 64 + lane] : qc_tanh(g[0]);
+    float gb[NCH], gw4;
+    post_cotangents<N, NCH>(gb, gw4, g, ub, z, W4[m]);
+    float wg[N + 2];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const float w3 = W3[m * N + i];
+      float sum = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        qb[c][i] = fmaf(w3, gb[c], qb[c][i]);
+        sum = fmaf(gb[c], q[c][i], sum);
+      }
+      wg[i] = sum;
+    }
+    wg[N] = gb[0];
+    wg[N + 1] = gw4;
+#pragma unroll
+    for (int k = 0; k < N + 2; ++k) wg[k] = qc_wave_sum_to_lane63(wg[k]);
+    if (lane == 63) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) row[L.oW3 + m * N + i] = wg[i];
+      row[L.ob3 + m] = wg[N];
+      row[L.oW4 + m] = wg[N + 1];
+    }
+  }
+  if constexpr (WPT == 4) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) s_buf[wave][c * N + i][lane] = qb[c][i];
+    __syncthreads();
+    if (live) {
+      for (int f = wave; f < NCH * N; f += QC_MS)
+        qbar[(int64_t)f * B + p] = (s_buf[0][f][lane] + s_buf[1][f][lane]) + (s_buf[2][f][lane] + s_buf[3][f][lane]);
+    }
+  } else {
+    if (live) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < N; ++i) qbar[((int64_t)c * N + i) * B + p] = qb[c][i];
+    }
+  }
+}
+
+// hidden widths the fused post kernel parks tanh values for (LDS: H x 64 floats per residual tile)
+constexpr int QC_POST_FUSED_MAXH = 128;
+
+template <int N, int NCH>
+__global__ void __launch_bounds__(256) k_post_fused(const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
+                                                    QcPde pde, const float* __restrict__ qjets, float* __restrict__ out_u,
+                                                    float* __restrict__ out_res, float* __restrict__ qbar,
+                                                    float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B) {
+  extern __shared__ float s_dyn[];
+  if constexpr (NCH == 6) k_post_fused_body<N, 6, 4>(blockIdx.x, X, prm, L, pde, qjets, out_u, out_res, qbar, part, part_stride, row0, B, s_dyn);
+  else k_post_fused_body<N, 1, 1>(blockIdx.x, X, prm, L, pde, qjets, out_u, out_res, qbar, part, part_stride, row0, B, s_dyn);
+}
+
 // ================================================================== residual + value tiles in ONE launch
 // The fused step's two pipelines (65 536 residual points with 6 channels, 2 x 21 845 boundary / initial points with
 // the value channel) are independent until the row reduction.  Launching each stage once over the blocks of BOTH
@@ -769,6 +978,17 @@ __global__ void __launch_bounds__(256) k_post_both(const float* __restrict__ prm
 }
 
 template <int N>
+__global__ void __launch_bounds__(256) k_post_fused_both(const float* __restrict__ prm, QcLayout L, QcPde pde, QcPostSeg r,
+                                                         QcPostSeg v, float* __restrict__ part, int64_t part_stride,
+                                                         int n_val) {
+  extern __shared__ float s_dyn[];
+  if ((int)blockIdx.x >= n_val)
+    k_post_fused_body<N, 6, 4>(blockIdx.x - n_val, r.X, prm, L, pde, r.qjets, r.ub, r.rb, r.qbar, part, part_stride, r.row0, r.B, s_dyn);
+  else
+    k_post_fused_body<N, 1, 1>(blockIdx.x, v.X, prm, L, pde, v.qjets, v.ub, nullptr, v.qbar, part, part_stride, v.row0, v.B, s_dyn);
+}
+
+template <int N>
 __global__ void k_post_wg_both(const float* __restrict__ prm, QcLayout L, QcPde pde, QcPostSeg r, QcPostSeg v,
                                float* __restrict__ part, int64_t part_stride, int HB, int PS, int n_val) {
   if ((int)blockIdx.x >= n_val)
@@ -806,6 +1026,11 @@ static inline void hidden_geometry(int H, int* HB, int* PS, int* threads) {
     *PS = ps >= 4 ? 4 : (ps >= 2 ? 2 : 1);
   }
   *threads = 64 * qc_ceil_div(*HB * *PS, 64);
+}
+
+static inline bool post_fused_ok(const QcLayout& L) {
+  static const bool split = [] { const char* e = getenv("QC_POST_SPLIT"); return e && e[0] == '1'; }();
+  return !split && L.H <= QC_POST_FUSED_MAXH;
 }
 
 int qc_mlp_pre_fwd(const float* X, const float* prm, QcLayout L, float* ajets, int64_t B, int nch,
@@ -848,28 +1073,37 @@ int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pd
   const float* ub_src = (mode == 1 || mode == 3) ? in_ubar : out_u;
   const float* rb_src = mode == 1 ? in_rbar : out_res;
   const int gen = mode == 3 ? 1 : 0;
+  const bool fused = post_fused_ok(L);
 #define LAUNCH(NN, CC, MM)                                                                              \
   hipLaunchKernelGGL((k_post<NN, CC, MM>), dim3(tiles), dim3(256), 0, st, X, prm, L, pde, qjets, out_u,  \
                      out_res, in_ubar, in_rbar, qbar, part, part_stride, row0, B)
 #define LAUNCH_WG(NN, CC)                                                                               \
   hipLaunchKernelGGL((k_post_wg<NN, CC>), dim3(tiles), dim3(threads), sh, st, prm, L, pde, qjets,        \
                      ub_src, (CC == 6 ? rb_src : nullptr), part, part_stride, row0, B, HB, PS, gen)
+  /* the step's form (mode 2): one kernel, lane = point in both phases (k_post_fused_body); QC_POST_SPLIT=1 keeps the pair */ \
+#define LAUNCH_FUSED(NN, CC)                                                                            \
+  hipLaunchKernelGGL((k_post_fused<NN, CC>), dim3(CC == 6 ? tiles : qc_ceil_div(tiles, 4)), dim3(256),   \
+                     CC == 6 ? (size_t)L.H * 64 * sizeof(float) : 0, st, X, prm, L, pde, qjets, out_u,   \
+                     out_res, qbar, part, part_stride, row0, B)
 #define CALL(NN)                                                         \
   if (nch == 6) {                                                        \
     if (mode == 0) LAUNCH(NN, 6, 0);                                     \
     else if (mode == 1) { LAUNCH(NN, 6, 1); LAUNCH_WG(NN, 6); }          \
     else if (mode == 3) { LAUNCH(NN, 6, 3); LAUNCH_WG(NN, 6); }          \
     else if (mode == 4) LAUNCH(NN, 6, 4);                                \
+    else if (fused) LAUNCH_FUSED(NN, 6);                                 \
     else { LAUNCH(NN, 6, 2); LAUNCH_WG(NN, 6); }                         \
   } else {                                                               \
     if (mode == 0) LAUNCH(NN, 1, 0);                                     \
     else if (mode == 1) { LAUNCH(NN, 1, 1); LAUNCH_WG(NN, 1); }          \
+    else if (fused) LAUNCH_FUSED(NN, 1);                                 \
     else { LAUNCH(NN, 1, 2); LAUNCH_WG(NN, 1); }                         \
   }
   QC_MLP_DISPATCH(L.n, CALL)
 #undef CALL
 #undef LAUNCH
 #undef LAUNCH_WG
+#undef LAUNCH_FUSED
   return QC_OK;
 }
 
@@ -917,10 +1151,16 @@ int qc_mlp_post_both(const float* prm, QcLayout L, QcPde pde, const float* Xr, c
   const size_t sh = (size_t)PS * (L.n + 2) * HB * sizeof(float);
   const int nv4 = qc_ceil_div(nv, 4);   // point kernel: 4 value tiles per block, one per wave
   const QcPostSeg r = {Xr, qjr, ubr, rbr, qbr, row0_r, Br}, v = {Xv, qjv, ubv, nullptr, qbv, row0_v, Bv};
-#define CALL(NN)                                                                                                      \
-  hipLaunchKernelGGL((k_post_both<NN>), dim3(nr + nv4), dim3(256), 0, st, prm, L, pde, r, v, part, part_stride, nv4); \
-  hipLaunchKernelGGL((k_post_wg_both<NN>), dim3(nr + nv), dim3(threads), sh, st, prm, L, pde, r, v, part, part_stride, \
-                     HB, PS, nv);
+  const bool fused = post_fused_ok(L);
+#define CALL(NN)                                                                                                        \
+  if (fused) {                                                                                                          \
+    hipLaunchKernelGGL((k_post_fused_both<NN>), dim3(nr + nv4), dim3(256), (size_t)L.H * 64 * sizeof(float), st, prm, L, \
+                       pde, r, v, part, part_stride, nv4);                                                              \
+  } else {                                                                                                              \
+    hipLaunchKernelGGL((k_post_both<NN>), dim3(nr + nv4), dim3(256), 0, st, prm, L, pde, r, v, part, part_stride, nv4); \
+    hipLaunchKernelGGL((k_post_wg_both<NN>), dim3(nr + nv), dim3(threads), sh, st, prm, L, pde, r, v, part, part_stride, \
+                       HB, PS, nv);                                                                                     \
+  }
   QC_MLP_DISPATCH(L.n, CALL)
 #undef CALL
   return QC_OK;

@@ -25,7 +25,8 @@ def _flat_param_list(model):
 
 
 class _ValueFn(torch.autograd.Function):
-    """X (B,3) -> u (B,1); differentiable w.r.t. the solver parameters (not w.r.t. X)."""
+    """X (B,3) -> u (B,1); differentiable w.r.t. the solver parameters.  Inputs that require gradients take
+    ``DVPDESolver._forward_wrt_inputs`` instead (value channel only here: one sixth of the work)."""
 
     @staticmethod
     def forward(ctx, X, solver, *params):
@@ -95,6 +96,42 @@ class _JetsFn(torch.autograd.Function):
         eng.refresh_gates()
         d_flat = eng.backward(Xc, ajets, qjets, g.to(torch.float32).t().contiguous(), None, _engine.NCH, ujets=True)
         return None, None, d_flat
+
+
+class _NoSecond(torch.autograd.Function):
+    """Zero-valued guard of the input expansion (``DVPDESolver._forward_wrt_inputs``): contributes nothing to u and to its
+    first derivatives, and makes every second derivative the kernels do NOT carry come out as NaN instead of a silent
+    zero.  ``mask`` (k, k) marks the carried second derivatives (the diagonal entries of the coordinate slots that own
+    a second-derivative channel)."""
+
+    @staticmethod
+    def forward(ctx, delta, mask):
+        ctx.mask = mask
+        ctx.save_for_backward(delta)
+        return delta.new_zeros(delta.shape[0], 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (delta,) = ctx.saved_tensors
+        return _NoSecondGrad.apply(g, delta, ctx.mask), None
+
+
+class _NoSecondGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g, delta, mask):
+        ctx.mask = mask
+        return torch.zeros_like(delta)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, c):
+        # c (B, k): cotangent of the first-derivative vector.  Entry j of the result is sum_i c_i d2u/dX_i dX_j of the
+        # terms this guard stands for: NaN wherever a requested (i, j) is not carried
+        mask = ctx.mask.to(c.device)
+        asked = (c != 0).to(c.dtype)                       # (B, k)
+        missing = asked @ (~mask).to(c.dtype)              # (B, k): > 0 where column j meets an uncarried (i, j)
+        out = torch.where(missing > 0, torch.full_like(c, float("nan")), torch.zeros_like(c))
+        return None, out, None
 
 
 class DVPDESolver(nn.Module):
@@ -297,11 +334,35 @@ class DVPDESolver(nn.Module):
             self._engine_for(x.device)
             if x.shape[1] != self.input_dim:
                 raise ValueError(f"Expected input of shape (B, {self.input_dim}), got {tuple(x.shape)}")
+            if x.requires_grad and torch.is_grad_enabled():
+                return self._forward_wrt_inputs(x)
             return _ValueFn.apply(x, self, *_flat_param_list(self))
         except Exception as e:
             if self.logger is not None:
                 self.logger.print(f"Forward pass failed: {str(e)}")
             raise
+
+    def _forward_wrt_inputs(self, x: torch.Tensor) -> torch.Tensor:
+        """u (B, 1) as an ordinary autograd graph in the INPUTS as well (reference nn/DVPDESolver.py:81-110 is a plain
+        differentiable module, and trainer/diffusion_train.py:37-39 / nn/pde.py:59-70 differentiate it w.r.t. t, x, y).
+
+        The kernels carry six derivative channels (u, u_t, u_x, u_y, u_xx, u_yy; for a two-input model u, u_a, u_b,
+        u_aa, u_bb).  They are evaluated once by ``jets`` (differentiable w.r.t. the parameters with a cotangent per
+        channel) and u is returned as its own second-order expansion around the input,
+            u(X) + sum_k u_k d_k + 1/2 sum_k u_kk d_k^2,     d = X - X.detach()  (zero-valued, carries the graph),
+        so ``autograd.grad(u, x, create_graph=True)`` is u_x, ``autograd.grad(u_x, x)`` is u_xx, and ``loss.backward()``
+        through either reaches the parameters - exactly the derivatives the reference's operators request.  Second
+        derivatives without a channel (u_tt of a three-input model, mixed ones) come out as NaN, not zero (_NoSecond)."""
+        uj = self.jets(x, 0)                                # (B, 6), differentiable w.r.t. the parameters
+        d = x - x.detach()
+        k = self.input_dim
+        first = uj[:, 1:4] if k == 3 else uj[:, 2:4]        # (t, x, y) slots, or (a, b) in the (x, y) slots
+        second = uj[:, 4:6]
+        dd = d[:, -2:]                                      # the coordinates that own a second-derivative channel
+        u = uj[:, 0:1] + (first * d).sum(1, keepdim=True) + 0.5 * (second * dd * dd).sum(1, keepdim=True)
+        mask = torch.zeros(k, k, dtype=torch.bool)
+        mask[k - 2, k - 2] = mask[k - 1, k - 1] = True
+        return u + _NoSecond.apply(d, mask)
 
     def residual(self, X: torch.Tensor, D=0.01, v_x=1.0, v_y=1.0, sigma=(1.0, 1.0, 1.0)):
         """(u, residual) at X (B,3) with the derivative channels carried through the HIP kernels —
