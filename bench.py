@@ -130,23 +130,29 @@ def time_kernels(tr, reps=20):
         e1.record()
         e1.synchronize()
         out[name] = e0.elapsed_time(e1) / reps
-    # the stages IN SEQUENCE (step order, every kernel behind its true predecessor: cache state and clocks of a real
-    # step), one event between consecutive stages; an event costs ~1 us of queue time, so these are upper bounds
+    # the stages IN SEQUENCE (step order, every kernel behind its true predecessor: the cache state and clocks of a real
+    # step).  One event pair around `reps` repetitions of the whole five-stage sequence - an event between consecutive
+    # stages costs 3-4 us of queue time, as much as a third of a stage - and the sequence total is distributed over the
+    # stages in proportion to their isolated durations.
     seq = {}
     if "stage_pre_fwd" in calls:
         order = ["stage_pre_fwd", "stage_circuit_fwd", "stage_post", "stage_circuit_bwd", "stage_pre_bwd"]
-        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(order) + 1)] for _ in range(reps)]
         for _ in range(3):
             for name in order:
                 calls[name]()
-        for r in range(reps):
-            ev[r][0].record()
-            for k, name in enumerate(order):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            for name in order:
                 calls[name]()
-                ev[r][k + 1].record()
-        ev[-1][-1].synchronize()
-        for k, name in enumerate(order):
-            seq[name] = sum(ev[r][k].elapsed_time(ev[r][k + 1]) for r in range(reps)) / reps
+        e1.record()
+        e1.synchronize()
+        total = e0.elapsed_time(e1) / reps
+        iso = sum(out[name] for name in order)
+        for name in order:
+            seq[name] = out[name] * total / iso
+        seq["_sequence_total"] = total
+        seq["_isolated_total"] = iso
     return out, seq
 
 
@@ -326,6 +332,7 @@ def launch_ranks(a):
         cmd += ["--batch-per-gpu", str(a.batch_per_gpu)]
     if a.no_cpu_baseline:
         cmd += ["--no-cpu-baseline"]
+    cmd += ["--collective", a.collective, "--windows", str(a.windows)]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "4")
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -350,6 +357,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
     ap.add_argument("--windows", type=int, default=4, help="extra timed windows of K steps (min / median reported beside the line)")
+    ap.add_argument("--collective", choices=("torch", "rccl"), default=os.environ.get("QC_DP_COLLECTIVE", "torch"),
+                    help="N > 1: the step's all-reduce through torch.distributed (default) or inside the library call "
+                         "(qc_step_desc.comm: RCCL on the step's own stream, one host call per step)")
     a = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -375,6 +385,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    os.environ["QC_DP_COLLECTIVE"] = a.collective          # read by FusedTrainer
     per_gpu = a.batch_per_gpu or (65536 if world == 1 else 131072)
     args = base_args()
     global_batch = per_gpu * world
@@ -394,7 +405,7 @@ def main():
         # kernel durations used for the roofline: in-sequence (step order) where the step runs its merged stages - every
         # stage is ONE launch (the post stage, too, since round 3) - else each kernel back to back on warm buffers
         kt = dict(kt_iso)
-        kt.update(kt_seq)
+        kt.update({k: v for k, v in kt_seq.items() if not k.startswith("_")})
         dom = max((k for k in kt if k in flops and k.startswith("stage_") == merged), key=lambda k: kt[k])
         stages = {k: {"ms": kt[k], "ms_isolated": kt_iso[k], "launches": 1,
                       "frac": flops[k] * tr.B_res / (kt[k] * 1e-3) / 1e12 / PEAK_F32_TFLOPS}
@@ -416,6 +427,7 @@ def main():
             "config": {"workload": f"{cfg_name}: DV solver, 4 qubits, cascade, 1 layer, H=50, "
                                    f"{per_gpu} residual + 2x{per_gpu // 3} BC/IC points per GPU",
                        "global_batch": global_batch, "per_gpu_batch": per_gpu, "parallelism": f"dp{world}",
+                       "collective": (a.collective if world > 1 else None),
                        "total_points_per_s": a.steps * (global_batch + 2 * (global_batch // 3)) / dt,
                        "final_loss": rec["loss"], "host_enqueue_ms_per_step": t_enqueue / a.steps * 1e3,
                        "preroll_steps_untimed": tr.bench_info["preroll_steps"], "windows_ms_per_step": wins},
@@ -425,7 +437,8 @@ def main():
                          "traffic_source": (TRAFFIC_FILE + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)")
                          if traffic.get(dom) else None,
                          "kernel_ms": kt[dom], "kernel_ms_isolated": kt_iso[dom],
-                         "kernel_timing": "HIP events between consecutive stages run in step order (in-sequence)" if kt_seq
+                         "kernel_timing": "HIP events around the five stages run back to back in step order; the sequence total distributed "
+                                          "in proportion to the stages' isolated durations" if kt_seq
                                           else "HIP events around back-to-back launches of the kernel",
                          "algorithmic_flops_per_launch": flops[dom] * tr.B_res,
                          "stages": stages,

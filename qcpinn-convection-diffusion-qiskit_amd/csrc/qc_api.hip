@@ -51,9 +51,18 @@ static inline bool use_h2(const qc_program* p) {
   }();
   return p->h2 != nullptr && !p->amplitude && !off;
 }
+// Budget of the resident per-tile stores: QC_HBM_KEEP_GB (default 96), never more than 85 % of the memory that is free
+// on the current device when a workspace is sized (a smaller or partly occupied GPU gets fewer resident tiles, not an
+// allocation failure).
 static inline double hbm_budget_bytes() {
   static const double cap_gb = [] { const char* e = getenv("QC_HBM_KEEP_GB"); return e ? atof(e) : 96.0; }();
-  return cap_gb * 1073741824.0;
+  double b = cap_gb * 1073741824.0;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+    const double avail = 0.85 * (double)free_b;
+    if (avail < b) b = avail;
+  }
+  return b;
 }
 
 // A side stream per device so the (small) boundary/initial-value pipeline of a step can overlap the
@@ -264,7 +273,13 @@ static size_t h2_min_bytes(const qc_program* p) { return (qc_h2_bytes(p, p->h2, 
 static size_t step_circuit_bytes(const qc_program* p, int64_t B_res, int64_t B_val = 0) {
   if (use_hbm(p->n_qubits) && use_h2(p)) {
     const size_t all = h2_res_bytes(p, B_res) + h2_val_bytes(p, B_val);
-    return (double)all <= hbm_budget_bytes() ? (all > h2_min_bytes(p) ? all : h2_min_bytes(p)) : h2_min_bytes(p);
+    const double budget = hbm_budget_bytes();
+    if ((double)all <= budget) return all > h2_min_bytes(p) ? all : h2_min_bytes(p);
+    // not everything fits: as many six-channel tiles as the budget holds, shared by both pipelines (one launch
+    // sequence per group of resident tiles, the adjoint pass recomputes its group's forward pass)
+    const int64_t fit = qc_h2_tiles_that_fit(p, p->h2, 6, true, (size_t)budget);
+    const size_t some = (qc_h2_bytes(p, p->h2, 6, true, fit < 1 ? 1 : fit) + 255) & ~(size_t)255;
+    return some > h2_min_bytes(p) ? some : h2_min_bytes(p);
   }
   // round-1 kernels, n >= 9: the per-tile scratch, plus (when it fits the budget) one [chi | lam] slot per residual tile
   // so the adjoint pass of the step starts from the forward pass's final states instead of recomputing them

@@ -532,6 +532,17 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
       h2s_for<0, R>([&](auto Q) { xz[Q] = *reinterpret_cast<const qf2*>(g0 + (td0 | ST::lin_dep(Q))); });
     }
   }
+  // backward, last stage, direct loads: the NEXT channel's final amplitudes are requested while this channel's sweep runs
+  // (two waves per SIMD do not cover an HBM round trip on their own: load, sweep, store, load ... left the memory
+  // system idle during every sweep)
+  constexpr bool PREF = BWD && LAST && din && NCH > 1;
+  qf2 nxt[PREF ? R : 1];
+  if constexpr (PREF) {
+    using RD0 = H2sRound<PL, S, RF>;
+    const int al0 = abase | h2s_deposit<typename RD0::LaneG, LBITS>(tid);
+    const Cplx* g1 = chi_of(1);   // the sweep's first channel
+    h2s_for<0, R>([&](auto Q) { nxt[Q] = *reinterpret_cast<const qf2*>(g1 + RD0::dr(Q) + al0); });
+  }
   struct LinRBP { static constexpr int at(int j) { return H2sStage<PL, S>::LBITS + j; } };
   struct LinLK { static constexpr int at(int k) { return k; } };
 
@@ -635,7 +646,8 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
               constexpr int q = Q;
               qf2 x, y;
               if constexpr (LAST) {
-                x = c == 0 ? xz[q] : *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
+                if constexpr (PREF) x = c == 0 ? xz[q] : nxt[q];
+                else x = c == 0 ? xz[q] : *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
                 y = build_lam(c, lbase | RD::roff(q), x, xz[q], l0acc[q]);
               } else {
                 x = *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
@@ -644,6 +656,12 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
               v[0].a[q] = x;
               v[1].a[q] = y;
             });
+            if constexpr (PREF) {
+              if (ci + 2 < NCH) {   // channels run 1, 2, ..., NCH - 1, 0: request channel ci + 2 now
+                const Cplx* gn = chi_of(ci + 2);
+                h2s_for<0, R>([&](auto Q) { nxt[Q] = *reinterpret_cast<const qf2*>(gn + RD::dr(Q) + alane); });
+              }
+            }
           }
         } else {
           h2s_for<0, R>([&](auto Q) {

@@ -96,6 +96,49 @@ def _trig_features(x: torch.Tensor) -> torch.Tensor:
     return phi
 
 
+class _LayerVjpFn(torch.autograd.Function):
+    """(x, theta, gq) -> (gx, gtheta): the reverse pass of the layer as a function that is differentiable ONCE more.
+    Serves ``create_graph=True`` where the trigonometric interpolant does not reach (num_qubits > 7, amplitude
+    encoding): the second-order quantities come from the derivative-channel kernels.  With a cotangent cx of gx,
+        s = sum(gx * cx) = sum_p gq_p . (J(a_p) cx_p)
+    is the first-derivative channel of the circuit along the direction cx, so ONE forward / reverse pass of the jet
+    kernels with (a, da = cx) and the cotangent gq on that channel returns ds/da (the Hessian-vector product),
+    ds/dgq = J cx (the channel itself) and ds/dtheta (reference use: nn/pde.py:59-70 on a user-composed model).
+    Third-order derivatives (a loss.backward() THROUGH second input derivatives) are not available on this path."""
+
+    @staticmethod
+    def forward(ctx, x, params, gq, layer):
+        circ = layer._circuit_for(x.device)
+        angles = x.detach().to(torch.float32).t().contiguous()
+        theta = params.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        circ.prepare(theta)
+        d_angles, d_theta = circ.backward_expval(angles, gq.detach().to(torch.float32).contiguous())
+        ctx.circ, ctx.layer = circ, layer
+        ctx.save_for_backward(x, params, gq)
+        return d_angles.t().to(x.dtype), d_theta.reshape(params.shape).to(params.device)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, cx, cp):
+        x, params, gq = ctx.saved_tensors
+        circ = ctx.circ
+        if cp is not None and bool((cp != 0).any()):
+            raise NotImplementedError("second derivatives with respect to the circuit parameters (theta-Hessians) are not "
+                                      "provided by DVQuantumLayer")
+        n, B = x.shape[1], x.shape[0]
+        theta = params.detach().to(device=x.device, dtype=torch.float32).reshape(-1).contiguous()
+        circ.prepare(theta)
+        aj = torch.zeros(6, n, B, dtype=torch.float32, device=x.device)
+        aj[0] = x.detach().to(torch.float32).t()
+        if cx is not None:
+            aj[1] = cx.detach().to(torch.float32).t()
+        qj = circ.forward_jets(aj)                       # qj[1] = J cx
+        w = torch.zeros_like(aj)
+        w[1] = gq.detach().to(torch.float32)
+        abar, d_theta = circ.backward_jets(aj, w)        # abar[0] = d s / d a, d_theta = d s / d theta
+        return abar[0].t().to(x.dtype), d_theta.reshape(params.shape).to(params.device), qj[1].to(gq.dtype), None
+
+
 class _ExpvalFn(torch.autograd.Function):
     """angles (B, n), theta (L, P) -> <Z> (n, B).  Forward and the ordinary reverse pass are the HIP
     statevector kernels.  Under ``create_graph=True`` (the reference's nn/pde.py:59-70 usage on an
@@ -120,10 +163,10 @@ class _ExpvalFn(torch.autograd.Function):
         circ, layer = ctx.circ, ctx.layer
         if torch.is_grad_enabled():          # create_graph=True: the result must itself be differentiable
             if layer.encoding == "amplitude" or layer.num_qubits > TRIG_INTERP_MAX_QUBITS:
-                raise NotImplementedError(
-                    "higher-order derivatives through DVQuantumLayer are provided for angle encoding and "
-                    f"num_qubits <= {TRIG_INTERP_MAX_QUBITS}; DVPDESolver.residual / diffusion_operator on a "
-                    "DVPDESolver use the fused derivative channels for any supported size")
+                # second-order input derivatives from the derivative-channel kernels (any size, both encodings); the
+                # interpolant below additionally carries third and higher orders
+                gx, gp = _LayerVjpFn.apply(x, params, grad_out, layer)
+                return (gx if x.requires_grad else None), (gp if params.requires_grad else None), None
             q = layer.trig_interpolant(x, params)
             wanted = [t for t in (x, params) if t.requires_grad]
             got = list(torch.autograd.grad(q, wanted, grad_out.to(q.dtype), create_graph=True, allow_unused=True))

@@ -90,10 +90,44 @@ def test_generic_diffusion_operator_on_composite_model(gpu_device, tmp_path):
     assert np.abs(g - z["grad"]).max() < 2e-4 * gs
 
 
-def test_higher_order_refused_where_not_provided(gpu_device):
-    args = base_args(encoding="amplitude")
+@pytest.mark.parametrize("over,B", [({"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"}, 5),
+                                    ({"encoding": "amplitude"}, 9),
+                                    ({"num_qubits": 9, "q_ansatz": "cascade"}, 3)])
+def test_second_derivatives_beyond_the_interpolant_come_from_the_derivative_channels(over, B, gpu_device):
+    """num_qubits > 7 or amplitude encoding: the create_graph=True reverse pass of the layer is differentiable once more
+    through the jet kernels (Hessian-vector products, their theta-gradient, J c).  Same quantities as the oracle's
+    torch double backward (reference nn/pde.py:59-70 on a user-composed model); third order is refused loudly."""
+    from oracle import solver as osolver
+    args = base_args(**over)
+    torch.manual_seed(3)
     layer = pkg("nn.DVQuantumLayer").DVQuantumLayer(args).to(gpu_device)
-    x = torch.rand(8, 4, device=gpu_device).requires_grad_(True)
-    q = layer(x)
-    with pytest.raises(NotImplementedError):
-        torch.autograd.grad(q.sum(), x, create_graph=True)
+    ref = osolver.OracleQuantumLayer(args)
+    with torch.no_grad():
+        ref.params.copy_(layer.params.cpu())
+    n = args["num_qubits"]
+    g0 = torch.Generator().manual_seed(5)
+    x0 = torch.rand(B, n, dtype=torch.float64, generator=g0) * 2.0 - 0.7
+    w = torch.rand(n, B, dtype=torch.float64, generator=g0)
+
+    def run(lay, x, wt):
+        x = x.clone().requires_grad_(True)
+        q = lay(x)
+        g, = torch.autograd.grad((q * wt.to(q.dtype)).sum(), x, create_graph=True)
+        lay.zero_grad()
+        s = (g * g).sum()
+        h, = torch.autograd.grad(s, x, retain_graph=True)
+        s.backward()
+        return q.detach(), g.detach(), h.detach(), lay.params.grad.detach().clone()
+
+    qo, go, ho, po = run(ref, x0, w)
+    qh, gh, hh, ph = run(layer, x0.to(gpu_device, torch.float32), w.to(gpu_device, torch.float32))
+    assert (qh.cpu().double() - qo).abs().max() < 1e-5
+    assert (gh.cpu().double() - go).abs().max() < 2e-5 * max(1.0, go.abs().max().item())
+    assert (hh.cpu().double() - ho).abs().max() < 1e-4 * max(1.0, ho.abs().max().item())
+    assert (ph.cpu().double() - po.double()).abs().max() < 2e-4 * max(1.0, po.abs().max().item())
+    # third order (differentiating the Hessian-vector product again) is not provided on this path
+    x = x0.to(gpu_device, torch.float32).requires_grad_(True)
+    g, = torch.autograd.grad(layer(x).sum(), x, create_graph=True)
+    h, = torch.autograd.grad((g * g).sum(), x, create_graph=True)
+    with pytest.raises(RuntimeError):
+        (h * h).sum().backward()

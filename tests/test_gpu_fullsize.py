@@ -42,9 +42,10 @@ def grads_for(model, X_ic, X_bc, X_res):
     n_res, n_ic, n_bc = X_res.shape[0], X_ic.shape[0], X_bc.shape[0]
     opt = engine.OptimState(eng.NP, 0.005, dev)
     fs = engine.FusedStep(eng, n_res, n_ic, n_bc, opt, (max(n_res, 1), max(n_ic, 1), max(n_bc, 1)))
-    if 4 <= fs.step_ws.numel() <= (1 << 28):       # (not the GB-sized stores of the full-size cases: fill time)
-        # poison the step workspace (kept-state stores): nothing may depend on what it held before the step, and rows
-        # of points beyond a ragged batch must be masked, not multiplied by zero cotangents
+    if fs.step_ws.numel() >= 4:
+        # poison the step workspace (kept-state stores; a device-side fill, ~20 ms for the 51 GB of config 5): nothing may
+        # depend on what it held before the step, and rows of points beyond a ragged batch must be masked, not
+        # multiplied by zero cotangents
         nfl = fs.step_ws.numel() // 4
         fs.step_ws[: 4 * nfl].view(torch.float32).fill_(float("nan"))
     if n_res:

@@ -50,6 +50,9 @@ def test_kept_state_gradient_equals_recompute_gradient(tag, over, gpu_device, tm
     n = int(d.n)
     full_bytes = int(d.circ_ws_bytes)
     assert full_bytes > 0, "this case must have a kept-state store"
+    # NaN-poison the store: unwritten rows of a ragged tile must be masked, never multiplied by zero cotangents
+    nfl = tr.fs.step_ws.numel() // 4
+    tr.fs.step_ws[: 4 * nfl].view(torch.float32).fill_(float("nan"))
     tr.fs.run(L.QC_PHASE_GRADS)
     torch.cuda.synchronize()
     kept = tr.fs.flat_grad.clone()
@@ -76,6 +79,42 @@ def test_kept_state_gradient_equals_recompute_gradient(tag, over, gpu_device, tm
         # register / lane families: the recompute is inlined into the adjoint kernel, where the compiler contracts
         # multiply-adds differently from the forward kernel that filled the store -> last-bit differences only
         assert diff <= 1e-7 * scale, diff
+
+
+@pytest.mark.parametrize("over,B", [({"num_qubits": 16, "q_ansatz": "cross_mesh"}, 72),     # BASELINE config 5's program
+                                    ({"num_qubits": 13, "q_ansatz": "cross_mesh"}, 70),
+                                    ({"num_qubits": 12, "num_quantum_layers": 2, "q_ansatz": "layered"}, 66)])
+def test_hbm_family_kept_equals_recompute_on_two_ragged_tiles(over, B, gpu_device):
+    """n >= 9, two 64-point tiles with a ragged second one (compile-time stage programs at n = 16 and 13, the plan
+    interpreter at n = 12 layered): the fused step with every tile's [chi | lam] slot resident vs the same step with a
+    ONE-tile workspace (the adjoint pass recomputes each tile's forward pass).  Same kernels, same fp32 values, same
+    order: bit-identical [grad | losses], with the store NaN-poisoned first."""
+    L = pkg("hip.lib")
+    engine = pkg("hip.engine")
+    X_ic, X_bc, X_res = _batches(B, 33)
+    model = make(gpu_device, **over)
+    dev = model._flat.device
+    eng = model._engine_for(dev)
+    eng.refresh_gates()
+    opt = engine.OptimState(eng.NP, 0.005, dev)
+    fs = engine.FusedStep(eng, B, X_ic.shape[0], X_bc.shape[0], opt, (B, X_ic.shape[0], X_bc.shape[0]))
+    fs.X_res[:B] = X_res.to(dev)
+    fs.X_val[:X_ic.shape[0]] = X_ic.to(dev)
+    fs.X_val[X_ic.shape[0]:X_ic.shape[0] + X_bc.shape[0]] = X_bc.to(dev)
+    full_bytes = int(fs.desc.circ_ws_bytes)
+    one = (int(eng.lib.qc_circuit_workspace_bytes(eng.circuit.handle, 6, 1)) + 255) & ~255
+    assert 0 < one < full_bytes
+    nfl = fs.step_ws.numel() // 4
+    fs.step_ws[: 4 * nfl].view(torch.float32).fill_(float("nan"))
+    fs.run(L.QC_PHASE_GRADS)
+    torch.cuda.synchronize()
+    kept = fs.flat_grad.clone()
+    assert torch.isfinite(kept).all()
+    fs.step_ws[: 4 * nfl].view(torch.float32).fill_(float("nan"))
+    fs.desc.circ_ws_bytes = one
+    fs.run(L.QC_PHASE_GRADS)
+    torch.cuda.synchronize()
+    assert torch.equal(kept, fs.flat_grad), (kept - fs.flat_grad).abs().max().item()
 
 
 @pytest.mark.parametrize("tag,over", KEPT_CASES[:2])

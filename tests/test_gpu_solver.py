@@ -76,6 +76,48 @@ def test_diffusion_operator_matches_reference_pde(tag, over, gpu_device, tmp_pat
     assert np.abs(g - z["grad"]).max() < 2e-4 * gs
 
 
+@pytest.mark.parametrize("tag,over", [("cascade_n4", {}), ("layered_n8", {"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"}),
+                                      ("cross_mesh_n16", {"num_qubits": 16, "q_ansatz": "cross_mesh"})])
+def test_forward_is_differentiable_in_its_inputs_like_the_reference_module(tag, over, gpu_device, tmp_path):
+    """The reference module is an ordinary autograd graph: trainer/diffusion_train.py:37-39 sets requires_grad on the
+    inputs and nn/pde.py:59-70 differentiates model(X) five times.  Here that ALGORITHM (the generic branch of
+    nn.pde.diffusion_operator: plain autograd.grad on model.forward, no fused dispatch) runs on the DVPDESolver and
+    must reproduce the fixture the reference's own nn/pde.py produced - u, residual, loss and the parameter gradient
+    of loss.backward() through the second derivatives."""
+    z = np.load(os.path.join(GOLDEN, f"operator_{tag}.npz"))
+    Solver = pkg("nn.DVPDESolver").DVPDESolver
+    pde = pkg("nn.pde")
+    data = pkg("data.diffusion_dataset")
+    torch.manual_seed(1)
+    model = Solver(base_args(**over), Log(tmp_path), device=gpu_device)
+    load_weights(model, z, "w__")
+    X = torch.from_numpy(z["X"]).to(gpu_device)
+    t, x, y = X[:, 0:1].clone(), X[:, 1:2].clone(), X[:, 2:3].clone()
+    plain = lambda inp: model(inp)                       # hides .residual / .quantum_layer: the generic autograd branch
+    u, res = pde.diffusion_operator(plain, t, x, y)
+    assert np.abs(u.detach().cpu().numpy() - z["u"]).max() < 2e-5
+    scale = max(1.0, np.abs(z["residual"]).max())
+    assert np.abs(res.detach().cpu().numpy() - z["residual"]).max() < 1e-4 * scale
+    loss = 2.0 * torch.nn.functional.mse_loss(res, data.r(X))
+    assert abs(loss.item() - float(z["loss"])) < 1e-4 * max(1.0, float(z["loss"]))
+    model.zero_grad()
+    loss.backward()
+    g = flat_grad(model).cpu().numpy()
+    assert np.abs(g - z["grad"]).max() < 2e-4 * max(1.0, np.abs(z["grad"]).max())
+    # first derivatives alone, and what the six channels do not carry
+    Xg = X.clone().requires_grad_(True)
+    uu = model(Xg)
+    g1, = torch.autograd.grad(uu.sum(), Xg, create_graph=True)
+    jets = model.jets(X, 0)
+    assert torch.allclose(g1.detach(), jets[:, 1:4].detach(), atol=1e-6)
+    h_t, = torch.autograd.grad(g1[:, 0].sum(), Xg, retain_graph=True)
+    assert torch.isnan(h_t).all()                        # u_tt, u_tx, u_ty: no channel -> NaN, never a silent zero
+    h_x, = torch.autograd.grad(g1[:, 1].sum(), Xg, retain_graph=True)
+    assert torch.allclose(h_x[:, 1], jets[:, 4].detach(), atol=1e-6) and torch.isnan(h_x[:, 0]).all()
+    # without requires_grad on the input the value-only kernels run (same numbers)
+    assert np.abs(model(X).detach().cpu().numpy() - u.detach().cpu().numpy()).max() < 2e-6
+
+
 @pytest.mark.parametrize("tag,over", [("cascade_n4_sigma", {}),
                                       ("layered_n8_sigma", {"num_qubits": 8, "num_quantum_layers": 2, "q_ansatz": "layered"})])
 def test_diffusion_operator_with_sigma_scalings_matches_reference_pde(tag, over, gpu_device, tmp_path):
