@@ -117,6 +117,36 @@ def test_hbm_family_kept_equals_recompute_on_two_ragged_tiles(over, B, gpu_devic
     assert torch.equal(kept, fs.flat_grad), (kept - fs.flat_grad).abs().max().item()
 
 
+def test_step_workspace_degrades_to_groups_of_tiles_when_the_budget_is_small(tmp_path):
+    """QC_HBM_KEEP_GB below what the batch needs (read once at library load, hence the child processes): the fused
+    step must size its workspace for as many tiles as fit (several launch sequences, forward recomputed per group),
+    not for one tile, and give the gradient of the all-resident step bit for bit."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, torch, numpy as np\n"
+        f"sys.path.insert(0, {here!r})\n"
+        "from test_gpu_fullsize import grads_for, make\n"
+        "from test_gpu_kept_state import _batches\n"
+        "dev = torch.device('cuda', 0)\n"
+        "model = make(dev, num_qubits=13, q_ansatz='cross_mesh')\n"
+        "X_ic, X_bc, X_res = _batches(330, 41)\n"
+        "eng = model._engine_for(dev)\n"
+        "print('WS', int(eng.lib.qc_step_workspace_bytes(eng.circuit.handle, 330, 220)))\n"
+        "np.save(sys.argv[1], grads_for(model, X_ic, X_bc, X_res).cpu().numpy())\n")
+    outs, sizes = [], []
+    for tag, env in (("all", {}), ("some", {"QC_HBM_KEEP_GB": "0.25"})):
+        f = str(tmp_path / f"g_{tag}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        sizes.append(int([ln for ln in r.stdout.splitlines() if ln.startswith("WS")][0].split()[1]))
+        outs.append(np.load(f))
+    assert sizes[1] < sizes[0] and sizes[1] > 0.1 * 0.25 * 2 ** 30      # smaller than all-resident, far more than one tile
+    assert sizes[1] <= 0.25 * 2 ** 30 + (1 << 20)
+    assert np.array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("tag,over", KEPT_CASES[:2])
 def test_multi_tile_train_loop_matches_reference_train(tag, over, gpu_device, tmp_path):
     z = np.load(os.path.join(GOLDEN, f"train_{tag}.npz"))
