@@ -35,7 +35,7 @@ PKG = "qcpinn-convection-diffusion-qiskit_amd"
 
 PEAK_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: fp32 vector peak (the kernels use no MFMA)
 PEAK_HBM_GBS = 8000.0
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
 
 
 def base_args(n=4, layers=1, ansatz="cascade", hidden=50):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define QC_ABI_VERSION 3
+#define QC_ABI_VERSION 4
 
 typedef struct qc_program qc_program; /* device-resident gate program (opaque) */
 
@@ -138,6 +138,16 @@ int qc_post(int mode, const float* X_dev, const float* params_dev, int H, int n,
             const qc_pde* pde, const float* qjets_dev, float* out_u_dev, float* out_res_dev,
             const float* in_ubar_dev, const float* in_rbar_dev, float* qbar_dev, float* part_dev,
             int64_t part_stride, int64_t row0, int64_t B, int nch, void* stream);
+
+/* K outputs behind one shared network: a post network Linear(n, H) -> Tanh -> Linear(H, K), 1 <= K <= 4 (the (u, v, p)
+ * model nn/pde.py:2-27 differentiates for Navier-Stokes).  params_dev: the flat vector of the single-output layout
+ * (its W4 / b4 slots are not read); w4k_dev = [K][H + 1] rows (W4[k][0..H-1], b4[k]).
+ * mode 4: out_u_dev = [K][6][B], the six derivative channels of every output, from ONE evaluation of the hidden layer;
+ * mode 3: its reverse, in_ubar_dev = [K][6][B] -> qbar jets [6][n][B], the tile rows of the shared parameters in
+ * part_dev (W3, b3 columns; the W4 / b4 columns are zeroed) and of the last layer in partk_dev ([rows][K * (H + 1)]). */
+int qc_post_multi(int mode, const float* params_dev, int H, int n, int n_theta, int K, const float* w4k_dev,
+                  const float* qjets_dev, float* out_u_dev, const float* in_ubar_dev, float* qbar_dev, float* part_dev,
+                  int64_t part_stride, float* partk_dev, int64_t partk_stride, int64_t row0, int64_t B, void* stream);
 
 /* ---- optimiser block of the step (trainer/diffusion_train.py:81-90) */
 int qc_reduce_rows(const float* part_dev, int64_t rows, int64_t stride, int ncols, float* out_dev, void* stream);

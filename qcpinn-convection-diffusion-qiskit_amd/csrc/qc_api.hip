@@ -447,6 +447,21 @@ int qc_post(int mode, const float* X, const float* prm, int H, int n, int n_thet
   return rc ? rc : after_launch();
 }
 
+int qc_post_multi(int mode, const float* prm, int H, int n, int n_theta, int K, const float* w4k, const float* qjets,
+                  float* out_u, const float* in_ubar, float* qbar, float* part, int64_t part_stride, float* partk,
+                  int64_t partk_stride, int64_t row0, int64_t B, void* stream) {
+  int rc = check_mlp(H, n, n_theta, B, 6);
+  if (rc) return rc;
+  const QcLayout L = make_layout(H, n, n_theta);
+  if ((mode != 3 && mode != 4) || K < 1 || K > 4 || !prm || !w4k || !qjets) return QC_ERR_ARG;
+  if (mode == 4 && !out_u) return QC_ERR_ARG;
+  if (mode == 3 && (!in_ubar || !qbar || !part || !partk || row0 < 0 || part_stride < L.NP || partk_stride < (int64_t)K * (H + 1)))
+    return QC_ERR_ARG;
+  rc = qc_mlp_post_multi(mode, prm, L, K, w4k, qjets, out_u, in_ubar, qbar, part, part_stride, partk, partk_stride, row0, B,
+                         (hipStream_t)stream);
+  return rc ? rc : after_launch();
+}
+
 int qc_reduce_rows(const float* part, int64_t rows, int64_t stride, int ncols, float* out, void* stream) {
   if (!part || !out || rows <= 0 || ncols <= 0 || stride < ncols) return QC_ERR_ARG;
   qc_opt_reduce_rows(part, rows, stride, ncols, out, (hipStream_t)stream);

@@ -102,6 +102,9 @@ int qc_mlp_pre_bwd(const float* X, const float* prm, QcLayout L, const float* ab
 int qc_mlp_post(int mode, const float* X, const float* prm, QcLayout L, QcPde pde, const float* qjets,
                 float* out_u, float* out_res, const float* in_ubar, const float* in_rbar, float* qbar,
                 float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, hipStream_t);
+int qc_mlp_post_multi(int mode, const float* prm, QcLayout L, int K, const float* w4k, const float* qjets, float* out_u,
+                      const float* ubar, float* qbar, float* part, int64_t part_stride, float* partk, int64_t partk_stride,
+                      int64_t row0, int64_t B, hipStream_t);
 int qc_opt_reduce_rows(const float* part, int64_t rows, int64_t stride, int ncols, float* out, hipStream_t);
 int qc_opt_fold_rows(float* part, int64_t rows, int64_t stride, int ncols, hipStream_t);
 int qc_opt_adam_fold(const float* part, int64_t stride, int RS, float* flat, int NP, float* prm, float* m, float* v,

@@ -32,6 +32,12 @@ __device__ __forceinline__ float qc_tanh(float x) {
   return 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
 }
 
+// register pairs for the contraction blocks of the six-channel kernels: two derivative channels per 64-bit register,
+// v_pk_fma_f32 with a broadcast scalar weight (two multiply-adds per instruction; csrc/qc_gates.h has the issue rates)
+typedef float mf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mf2 m_dup(const float a) { return (mf2){a, a}; }
+__device__ __forceinline__ mf2 m_fma(const mf2 a, const mf2 b, const mf2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // analytic solution and forcing term, data/diffusion_dataset.py:20-38
 __device__ __forceinline__ float analytic_u(float t, float x, float y) {
   const float dx = x - 0.5f, dy = y - 0.5f;
@@ -85,11 +91,13 @@ __device__ __forceinline__ void k_pre_fwd_body(const int64_t bid, const float* _
     x = X[pc * 3 + 1];
     y = X[pc * 3 + 2];
   }
-  float acc[NCH][N];
+  // six channels: the accumulators of channels (0,1), (2,3), (4,5) share a register pair (packed multiply-adds)
+  constexpr int NP2 = NCH == 6 ? 3 : 1;
+  mf2 acc2[NP2][N];
 #pragma unroll
-  for (int c = 0; c < NCH; ++c)
+  for (int cp = 0; cp < NP2; ++cp)
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[c][i] = 0.f;
+    for (int i = 0; i < N; ++i) acc2[cp][i] = (mf2){0.f, 0.f};
   const float* W1 = prm + L.oW1;
   const float* b1 = prm + L.ob1;
   const float* W2 = prm + L.oW2;
@@ -99,27 +107,24 @@ __device__ __forceinline__ void k_pre_fwd_body(const int64_t bid, const float* _
     const float w0 = W1[3 * m], w1 = W1[3 * m + 1], w2 = W1[3 * m + 2];
     const float h = fmaf(w0, t, fmaf(w1, x, fmaf(w2, y, b1[m])));
     const float z = qc_tanh(h);
-    float zc[NCH];
-    zc[0] = z;
     if constexpr (NCH == 6) {
       const float d1 = 1.f - z * z, d2 = -2.f * z * d1;
-      zc[1] = d1 * w0;
-      zc[2] = d1 * w1;
-      zc[3] = d1 * w2;
-      zc[4] = d2 * w1 * w1;
-      zc[5] = d2 * w2 * w2;
-    }
+      const mf2 zc2[3] = {(mf2){z, d1 * w0}, (mf2){d1 * w1, d1 * w2}, (mf2){d2 * w1 * w1, d2 * w2 * w2}};
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const float wi = W2[i * L.H + m];
+      for (int i = 0; i < N; ++i) {
+        const mf2 wi = m_dup(W2[i * L.H + m]);
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) acc[c][i] = fmaf(wi, zc[c], acc[c][i]);
+        for (int cp = 0; cp < 3; ++cp) acc2[cp][i] = m_fma(wi, zc2[cp], acc2[cp][i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) acc2[0][i].x = fmaf(W2[i * L.H + m], z, acc2[0][i].x);
     }
   }
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int i = 0; i < N; ++i) s_part[wave][c * N + i][lane] = acc[c][i];
+    for (int i = 0; i < N; ++i) s_part[wave][c * N + i][lane] = (c & 1) ? acc2[c >> 1][i].y : acc2[c >> 1][i].x;
   __syncthreads();
   if (p < B) {
     for (int f = wave; f < NCH * N; f += QC_MS) {
@@ -144,8 +149,11 @@ template <int N, int NCH>
 __device__ __forceinline__ void k_pre_bwd_body(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm, QcLayout L,
                           const float* __restrict__ abar, float* __restrict__ part, int64_t part_stride,
                           int64_t row0, int64_t B, int HB, int PS) {
+  // six channels: the cotangents of channels (0,1), (2,3), (4,5) of one wire sit side by side in LDS (one 64-bit
+  // broadcast read) and ride through the two contraction blocks as register pairs (packed multiply-adds)
+  constexpr int NP2 = NCH == 6 ? 3 : 1;
   __shared__ float sX[3][64];
-  __shared__ float sA[NCH * N][64];
+  __shared__ mf2 sA2[NP2 * N][64];   // [cp * N + i][point] = (abar of channel 2 cp, channel 2 cp + 1) (NCH = 1: .x only)
   extern __shared__ float s_acc[];  // [PS][4 + N][HB]
   const int64_t base = (int64_t)bid * 64;
   const int cnt = (int)((B - base) < 64 ? (B - base) : 64);
@@ -154,17 +162,21 @@ __device__ __forceinline__ void k_pre_bwd_body(const int64_t bid, const float* _
     sX[k][pp] = pp < cnt ? X[(base + pp) * 3 + k] : 0.f;
   }
   for (int i = threadIdx.x; i < NCH * N * 64; i += blockDim.x) {
-    const int f = i >> 6, pp = i & 63;
-    sA[f][pp] = pp < cnt ? abar[(int64_t)f * B + base + pp] : 0.f;
+    const int f = i >> 6, pp = i & 63;      // f = c * N + i
+    const int c = f / N, w = f % N;
+    const float v = pp < cnt ? abar[(int64_t)f * B + base + pp] : 0.f;
+    if (c & 1) sA2[(c >> 1) * N + w][pp].y = v;
+    else sA2[(c >> 1) * N + w][pp].x = v;
   }
   __syncthreads();
 
   const int grp = threadIdx.x / HB, m = threadIdx.x % HB;   // threads past HB * PS (block rounded up to waves) idle
   const int per = (64 + PS - 1) / PS;
   const int p0 = grp * per, p1 = (p0 + per) < cnt ? (p0 + per) : cnt;
-  float gW1[3] = {0.f, 0.f, 0.f}, gb1 = 0.f, gW2[N];
+  float gW1[3] = {0.f, 0.f, 0.f}, gb1 = 0.f;
+  mf2 gW2p[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) gW2[i] = 0.f;
+  for (int i = 0; i < N; ++i) gW2p[i] = (mf2){0.f, 0.f};
   if (grp < PS && m < L.H) {
     const float w0 = prm[L.oW1 + 3 * m], w1 = prm[L.oW1 + 3 * m + 1], w2 = prm[L.oW1 + 3 * m + 2];
     const float bb = prm[L.ob1 + m];
@@ -176,25 +188,25 @@ __device__ __forceinline__ void k_pre_bwd_body(const int64_t bid, const float* _
       const float h = fmaf(w0, t, fmaf(w1, x, fmaf(w2, y, bb)));
       const float z = qc_tanh(h);
       const float d1 = 1.f - z * z;
-      float zb[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < N; ++i) sum = fmaf(w2c[i], sA[c * N + i][pp], sum);
-        zb[c] = sum;
-      }
       if constexpr (NCH == 6) {
+        mf2 a2[3][N], zb2[3];
+#pragma unroll
+        for (int cp = 0; cp < 3; ++cp) {
+          zb2[cp] = (mf2){0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < N; ++i) {
+            a2[cp][i] = sA2[cp * N + i][pp];
+            zb2[cp] = m_fma(m_dup(w2c[i]), a2[cp][i], zb2[cp]);
+          }
+        }
         const float d2 = -2.f * z * d1;
         const float d3 = -2.f * (d1 * d1 + z * d2);
-        const float zc[6] = {z, d1 * w0, d1 * w1, d1 * w2, d2 * w1 * w1, d2 * w2 * w2};
+        const mf2 zc2[3] = {(mf2){z, d1 * w0}, (mf2){d1 * w1, d1 * w2}, (mf2){d2 * w1 * w1, d2 * w2 * w2}};
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
-          float sum = gW2[i];
+        for (int i = 0; i < N; ++i)
 #pragma unroll
-          for (int c = 0; c < 6; ++c) sum = fmaf(sA[c * N + i][pp], zc[c], sum);
-          gW2[i] = sum;
-        }
+          for (int cp = 0; cp < 3; ++cp) gW2p[i] = m_fma(a2[cp][i], zc2[cp], gW2p[i]);
+        const float zb[6] = {zb2[0].x, zb2[0].y, zb2[1].x, zb2[1].y, zb2[2].x, zb2[2].y};
         const float hb = zb[0] * d1 + (zb[1] * w0 + zb[2] * w1 + zb[3] * w2) * d2 +
                          (zb[4] * w1 * w1 + zb[5] * w2 * w2) * d3;
         gW1[0] += hb * t + zb[1] * d1;
@@ -202,9 +214,14 @@ __device__ __forceinline__ void k_pre_bwd_body(const int64_t bid, const float* _
         gW1[2] += hb * y + zb[3] * d1 + 2.f * zb[5] * d2 * w2;
         gb1 += hb;
       } else {
+        float zb0 = 0.f;
 #pragma unroll
-        for (int i = 0; i < N; ++i) gW2[i] = fmaf(sA[i][pp], z, gW2[i]);
-        const float hb = zb[0] * d1;
+        for (int i = 0; i < N; ++i) {
+          const float a = sA2[i][pp].x;
+          zb0 = fmaf(w2c[i], a, zb0);
+          gW2p[i].x = fmaf(a, z, gW2p[i].x);
+        }
+        const float hb = zb0 * d1;
         gW1[0] += hb * t;
         gW1[1] += hb * x;
         gW1[2] += hb * y;
@@ -219,7 +236,7 @@ __device__ __forceinline__ void k_pre_bwd_body(const int64_t bid, const float* _
     mine[2 * HB + m] = gW1[2];
     mine[3 * HB + m] = gb1;
 #pragma unroll
-    for (int i = 0; i < N; ++i) mine[(4 + i) * HB + m] = gW2[i];
+    for (int i = 0; i < N; ++i) mine[(4 + i) * HB + m] = gW2p[i].x + gW2p[i].y;
   }
   __syncthreads();
   float* row = part + (row0 + bid) * part_stride;
@@ -240,7 +257,7 @@ __device__ __forceinline__ void k_pre_bwd_body(const int64_t bid, const float* _
   }
   if (threadIdx.x < N) {  // b2 only feeds the value channel
     float sum = 0.f;
-    for (int pp = 0; pp < cnt; ++pp) sum += sA[threadIdx.x][pp];
+    for (int pp = 0; pp < cnt; ++pp) sum += sA2[threadIdx.x][pp].x;
     row[L.ob2 + threadIdx.x] = sum;
   }
 }
@@ -893,8 +910,7 @@ __device__ __forceinline__ void k_post_fused_body(const int64_t bid, const float
     }
     wg[N] = gb[0];
     wg[N + 1] = gw4;
-#pragma unroll
-    for (int k = 0; k < N + 2; ++k) wg[k] = qc_wave_sum_to_lane63(wg[k]);
+    qc_wave_sum_multi_to_lane63<N + 2>(wg);
     if (lane == 63) {
 #pragma unroll
       for (int i = 0; i < N; ++i) row[L.oW3 + m * N + i] = wg[i];
@@ -922,6 +938,146 @@ __device__ __forceinline__ void k_post_fused_body(const int64_t bid, const float
   }
 }
 
+// Residual tiles (six channels, four waves per tile) of the fused post stage with the three contraction blocks on
+// register PAIRS: channels (0,1), (2,3), (4,5) of the <Z> jets ride in the two halves of one 64-bit register, so
+//   g_c = sum_i W3[m][i] q_c[i],   qbar_c[i] += W3[m][i] gb_c,   sum_c gb_c q_c[i]
+// are v_pk_fma_f32 with a broadcast scalar weight: two multiply-adds per instruction at the issue cost of one and a
+// bit (csrc/qc_gates.h, tools/ubench/valu_issue.hip).  Same arithmetic as k_post_fused_body<N, 6, 4>, other order of the
+// sums over channel pairs in the weight-gradient products.
+
+template <int N>
+__device__ __forceinline__ void k_post_fused6_body(const int64_t bid, const float* __restrict__ X, const float* __restrict__ prm,
+                                                    QcLayout L, QcPde pde, const float* __restrict__ qjets,
+                                                    float* __restrict__ out_u, float* __restrict__ out_res,
+                                                    float* __restrict__ qbar, float* __restrict__ part, int64_t part_stride,
+                                                    int64_t row0, int64_t B, float* __restrict__ s_z) {
+  constexpr int NCH = 6;
+  __shared__ float s_buf[QC_MS][NCH * N][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = bid;
+  const int64_t p = tile * 64 + lane;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+  mf2 q2[3][N];
+#pragma unroll
+  for (int cp = 0; cp < 3; ++cp)
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      q2[cp][i] = (mf2){qjets[((int64_t)(2 * cp) * N + i) * B + pc], qjets[((int64_t)(2 * cp + 1) * N + i) * B + pc]};
+  const float* W3 = prm + L.oW3;
+  const float* b3 = prm + L.ob3;
+  const float* W4 = prm + L.oW4;
+  const int hq = (L.H + QC_MS - 1) / QC_MS;
+  const int m0 = wave * hq, m1 = (m0 + hq) < L.H ? (m0 + hq) : L.H;
+  auto preact = [&](int m, mf2 (&g2)[3]) {
+    g2[0] = (mf2){b3[m], 0.f};
+    g2[1] = g2[2] = (mf2){0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const mf2 w = m_dup(W3[m * N + i]);
+#pragma unroll
+      for (int cp = 0; cp < 3; ++cp) g2[cp] = m_fma(w, q2[cp][i], g2[cp]);
+    }
+  };
+  // ---------------- phase A
+  float u[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) u[c] = 0.f;
+  for (int m = m0; m < m1; ++m) {
+    mf2 g2[3];
+    preact(m, g2);
+    const float z = qc_tanh(g2[0].x);
+    s_z[m * 64 + lane] = z;
+    const float w4 = W4[m];
+    const float d1 = 1.f - z * z, d2 = -2.f * z * d1;
+    u[0] = fmaf(w4, z, u[0]);
+    u[1] = fmaf(w4, d1 * g2[0].y, u[1]);
+    u[2] = fmaf(w4, d1 * g2[1].x, u[2]);
+    u[3] = fmaf(w4, d1 * g2[1].y, u[3]);
+    u[4] = fmaf(w4, d2 * g2[1].x * g2[1].x + d1 * g2[2].x, u[4]);
+    u[5] = fmaf(w4, d2 * g2[1].y * g2[1].y + d1 * g2[2].y, u[5]);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) s_buf[wave][c][lane] = u[c];
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+    u[c] = (s_buf[0][c][lane] + s_buf[1][c][lane]) + (s_buf[2][c][lane] + s_buf[3][c][lane]);
+  __syncthreads();   // s_buf is reused for the qbar partials below
+  u[0] += prm[L.ob4];
+  // ---------------- residual / error / loss sums / per-point cotangent
+  const float t = X[pc * 3 + 0], x = X[pc * 3 + 1], y = X[pc * 3 + 2];
+  float* row = part + (row0 + tile) * part_stride;
+  const float res = pde.c_t * u[1] + pde.c_x * u[2] + pde.c_y * u[3] - (pde.d_xx * u[4] + pde.d_yy * u[5]);
+  const float target = pde.problem == QC_PB_PURE_DIFFUSION ? 0.f : analytic_r(t, x, y, pde.D, pde.vx, pde.vy);
+  const float e = live ? res - target : 0.f;
+  const float gsc = pde.w_res * e;
+  if (wave == 0) {
+    const float ls = qc_wave_sum_to_lane63(e * e * pde.inv_n_res);
+    if (lane == 63) {
+      row[L.NP + 0] = ls;
+      row[L.NP + 1] = 0.f;
+      row[L.NP + 2] = 0.f;
+      row[L.ob4] = 0.f;   // the loss sees u only through the residual: no cotangent on u itself
+    }
+    if (live) {           // the per-point cotangents (MODE 2 contract of qc_post)
+      out_u[p] = 0.f;
+      out_res[p] = gsc;
+    }
+  }
+  // ---------------- phase B
+  float ub[NCH];
+  expand_ub<NCH>(ub, 0.f, gsc, pde);
+  mf2 qb2[3][N];
+#pragma unroll
+  for (int cp = 0; cp < 3; ++cp)
+#pragma unroll
+    for (int i = 0; i < N; ++i) qb2[cp][i] = (mf2){0.f, 0.f};
+  for (int m = m0; m < m1; ++m) {
+    mf2 g2[3];
+    preact(m, g2);
+    const float g[NCH] = {0.f, g2[0].y, g2[1].x, g2[1].y, g2[2].x, g2[2].y};
+    const float z = s_z[m * 64 + lane];
+    float gb[NCH], gw4;
+    post_cotangents<N, NCH>(gb, gw4, g, ub, z, W4[m]);
+    const mf2 gb2[3] = {(mf2){gb[0], gb[1]}, (mf2){gb[2], gb[3]}, (mf2){gb[4], gb[5]}};
+    float wg[N + 2];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const mf2 w3 = m_dup(W3[m * N + i]);
+      mf2 acc = gb2[0] * q2[0][i];
+#pragma unroll
+      for (int cp = 0; cp < 3; ++cp) {
+        qb2[cp][i] = m_fma(w3, gb2[cp], qb2[cp][i]);
+        if (cp > 0) acc = m_fma(gb2[cp], q2[cp][i], acc);
+      }
+      wg[i] = acc.x + acc.y;
+    }
+    wg[N] = gb[0];
+    wg[N + 1] = gw4;
+    qc_wave_sum_multi_to_lane63<N + 2>(wg);
+    if (lane == 63) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) row[L.oW3 + m * N + i] = wg[i];
+      row[L.ob3 + m] = wg[N];
+      row[L.oW4 + m] = wg[N + 1];
+    }
+  }
+#pragma unroll
+  for (int cp = 0; cp < 3; ++cp)
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      s_buf[wave][(2 * cp) * N + i][lane] = qb2[cp][i].x;
+      s_buf[wave][(2 * cp + 1) * N + i][lane] = qb2[cp][i].y;
+    }
+  __syncthreads();
+  if (live) {
+    for (int f = wave; f < NCH * N; f += QC_MS)
+      qbar[(int64_t)f * B + p] = (s_buf[0][f][lane] + s_buf[1][f][lane]) + (s_buf[2][f][lane] + s_buf[3][f][lane]);
+  }
+}
+
 // hidden widths the fused post kernel parks tanh values for (LDS: H x 64 floats per residual tile)
 constexpr int QC_POST_FUSED_MAXH = 128;
 
@@ -931,8 +1087,171 @@ __global__ void __launch_bounds__(256) k_post_fused(const float* __restrict__ X,
                                                     float* __restrict__ out_res, float* __restrict__ qbar,
                                                     float* __restrict__ part, int64_t part_stride, int64_t row0, int64_t B) {
   extern __shared__ float s_dyn[];
-  if constexpr (NCH == 6) k_post_fused_body<N, 6, 4>(blockIdx.x, X, prm, L, pde, qjets, out_u, out_res, qbar, part, part_stride, row0, B, s_dyn);
+  if constexpr (NCH == 6) k_post_fused6_body<N>(blockIdx.x, X, prm, L, pde, qjets, out_u, out_res, qbar, part, part_stride, row0, B, s_dyn);
   else k_post_fused_body<N, 1, 1>(blockIdx.x, X, prm, L, pde, qjets, out_u, out_res, qbar, part, part_stride, row0, B, s_dyn);
+}
+
+// ================================================================== K outputs behind one shared network (Navier-Stokes)
+// A K-output post network Linear(n, H) -> Tanh -> Linear(H, K) (reference nn/pde.py:2-27 differentiates (u, v, p) of ONE
+// model) shares pre network, circuit and the hidden layer; only the last layer has a row per output.  The six
+// derivative channels of all K outputs come from one pass: f_c(m) (the hidden unit's channel values) is formed once,
+// u_k,c = sum_m W4[k][m] f_c(m).  w4k = [K][H + 1] rows (W4[k][0..H-1], b4[k]); the W4 / b4 slots of the flat vector
+// are not read.  MODE 4: forward, out = [K][6][B].  MODE 3: reverse, ubar = [K][6][B] -> qbar [6][n][B], the tile's row
+// of the shared parameters (W3, b3) in `part` and of the last layer in `partk` ([rows][K * (H + 1)]).  lane = point;
+// weight gradients by wave reductions as in k_post_fused_body.
+constexpr int QC_KMAX = 4;
+
+template <int N, int MODE>
+__global__ void __launch_bounds__(256) k_post_multi(const float* __restrict__ prm, QcLayout L, int K,
+                                                    const float* __restrict__ w4k, const float* __restrict__ qjets,
+                                                    float* __restrict__ out_u, const float* __restrict__ ubar,
+                                                    float* __restrict__ qbar, float* __restrict__ part, int64_t part_stride,
+                                                    float* __restrict__ partk, int64_t partk_stride, int64_t row0, int64_t B) {
+  constexpr int NCH = 6;
+  __shared__ float s_buf[QC_MS][NCH * (N > QC_KMAX ? N : QC_KMAX)][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t tile = blockIdx.x;
+  const int64_t p = tile * 64 + lane;
+  const bool live = p < B;
+  const int64_t pc = live ? p : B - 1;
+  float q[NCH][N];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[c][i] = qjets[((int64_t)c * N + i) * B + pc];
+  const float* W3 = prm + L.oW3;
+  const float* b3 = prm + L.ob3;
+  const int H1 = L.H + 1;
+  const int hq = (L.H + QC_MS - 1) / QC_MS;
+  const int m0 = wave * hq, m1 = (m0 + hq) < L.H ? (m0 + hq) : L.H;
+  auto hidden = [&](int m, float (&g)[NCH], float& z, float (&f)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      float sum = (c == 0) ? b3[m] : 0.f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) sum = fmaf(W3[m * N + i], q[c][i], sum);
+      g[c] = sum;
+    }
+    z = qc_tanh(g[0]);
+    const float d1 = 1.f - z * z, d2 = -2.f * z * d1;
+    f[0] = z;
+    f[1] = d1 * g[1];
+    f[2] = d1 * g[2];
+    f[3] = d1 * g[3];
+    f[4] = d2 * g[2] * g[2] + d1 * g[4];
+    f[5] = d2 * g[3] * g[3] + d1 * g[5];
+  };
+  if constexpr (MODE == 4) {
+    float u[QC_KMAX][NCH];
+#pragma unroll
+    for (int k = 0; k < QC_KMAX; ++k)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) u[k][c] = 0.f;
+    for (int m = m0; m < m1; ++m) {
+      float g[NCH], z, f[NCH];
+      hidden(m, g, z, f);
+#pragma unroll
+      for (int k = 0; k < QC_KMAX; ++k)
+        if (k < K) {
+          const float w4 = w4k[k * H1 + m];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) u[k][c] = fmaf(w4, f[c], u[k][c]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < QC_KMAX; ++k)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) s_buf[wave][k * NCH + c][lane] = u[k][c];
+    __syncthreads();
+    if (live) {
+      for (int f = wave; f < K * NCH; f += QC_MS) {
+        float v = (s_buf[0][f][lane] + s_buf[1][f][lane]) + (s_buf[2][f][lane] + s_buf[3][f][lane]);
+        if (f % NCH == 0) v += w4k[(f / NCH) * H1 + L.H];
+        out_u[(int64_t)f * B + p] = v;
+      }
+    }
+  } else {
+    float ub[QC_KMAX][NCH];
+#pragma unroll
+    for (int k = 0; k < QC_KMAX; ++k)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) ub[k][c] = (live && k < K) ? ubar[((int64_t)k * NCH + c) * B + pc] : 0.f;
+    float* row = part + (row0 + tile) * part_stride;
+    float* rowk = partk + (row0 + tile) * partk_stride;
+    if (wave == 0) {   // d / d b4[k] = sum of the points' cotangents of u_k
+#pragma unroll
+      for (int k = 0; k < QC_KMAX; ++k)
+        if (k < K) {
+          const float sb = qc_wave_sum_to_lane63(ub[k][0]);
+          if (lane == 63) rowk[k * H1 + L.H] = sb;
+        }
+    }
+    float qb[NCH][N];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) qb[c][i] = 0.f;
+    for (int m = m0; m < m1; ++m) {
+      float g[NCH], z, f[NCH];
+      hidden(m, g, z, f);
+      float ubw[NCH], gk[QC_KMAX];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) ubw[c] = 0.f;
+#pragma unroll
+      for (int k = 0; k < QC_KMAX; ++k) {
+        gk[k] = 0.f;
+        if (k < K) {
+          const float w4 = w4k[k * H1 + m];
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            ubw[c] = fmaf(w4, ub[k][c], ubw[c]);
+            gk[k] = fmaf(ub[k][c], f[c], gk[k]);
+          }
+        }
+      }
+      float gb[NCH], gw4;
+      post_cotangents<N, NCH>(gb, gw4, g, ubw, z, 1.f);
+      float wg[N + 1];
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const float w3 = W3[m * N + i];
+        float sum = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          qb[c][i] = fmaf(w3, gb[c], qb[c][i]);
+          sum = fmaf(gb[c], q[c][i], sum);
+        }
+        wg[i] = sum;
+      }
+      wg[N] = gb[0];
+      qc_wave_sum_multi_to_lane63<N + 1>(wg);
+#pragma unroll
+      for (int k = 0; k < QC_KMAX; ++k)
+        if (k < K) gk[k] = qc_wave_sum_to_lane63(gk[k]);
+      if (lane == 63) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) row[L.oW3 + m * N + i] = wg[i];
+        row[L.ob3 + m] = wg[N];
+#pragma unroll
+        for (int k = 0; k < QC_KMAX; ++k)
+          if (k < K) rowk[k * H1 + m] = gk[k];
+      }
+    }
+    if (threadIdx.x == 0) {   // the single-output slots of the flat layout are not parameters here
+      for (int m = 0; m < L.H; ++m) row[L.oW4 + m] = 0.f;
+      row[L.ob4] = 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int i = 0; i < N; ++i) s_buf[wave][c * N + i][lane] = qb[c][i];
+    __syncthreads();
+    if (live) {
+      for (int f = wave; f < NCH * N; f += QC_MS)
+        qbar[(int64_t)f * B + p] = (s_buf[0][f][lane] + s_buf[1][f][lane]) + (s_buf[2][f][lane] + s_buf[3][f][lane]);
+    }
+  }
 }
 
 // ================================================================== residual + value tiles in ONE launch
@@ -983,7 +1302,7 @@ __global__ void __launch_bounds__(256) k_post_fused_both(const float* __restrict
                                                          int n_val) {
   extern __shared__ float s_dyn[];
   if ((int)blockIdx.x >= n_val)
-    k_post_fused_body<N, 6, 4>(blockIdx.x - n_val, r.X, prm, L, pde, r.qjets, r.ub, r.rb, r.qbar, part, part_stride, r.row0, r.B, s_dyn);
+    k_post_fused6_body<N>(blockIdx.x - n_val, r.X, prm, L, pde, r.qjets, r.ub, r.rb, r.qbar, part, part_stride, r.row0, r.B, s_dyn);
   else
     k_post_fused_body<N, 1, 1>(blockIdx.x, v.X, prm, L, pde, v.qjets, v.ub, nullptr, v.qbar, part, part_stride, v.row0, v.B, s_dyn);
 }
@@ -1161,6 +1480,22 @@ int qc_mlp_post_both(const float* prm, QcLayout L, QcPde pde, const float* Xr, c
     hipLaunchKernelGGL((k_post_wg_both<NN>), dim3(nr + nv), dim3(threads), sh, st, prm, L, pde, r, v, part, part_stride, \
                        HB, PS, nv);                                                                                     \
   }
+  QC_MLP_DISPATCH(L.n, CALL)
+#undef CALL
+  return QC_OK;
+}
+
+// K-output post stage (k_post_multi): mode 4 forward / mode 3 reverse, six channels
+int qc_mlp_post_multi(int mode, const float* prm, QcLayout L, int K, const float* w4k, const float* qjets, float* out_u,
+                      const float* ubar, float* qbar, float* part, int64_t part_stride, float* partk, int64_t partk_stride,
+                      int64_t row0, int64_t B, hipStream_t st) {
+  if (K < 1 || K > QC_KMAX || L.H > 1024) return QC_ERR_UNSUPPORTED;
+  const int tiles = qc_ceil_div(B, 64);
+#define CALL(NN)                                                                                                     \
+  if (mode == 4) hipLaunchKernelGGL((k_post_multi<NN, 4>), dim3(tiles), dim3(256), 0, st, prm, L, K, w4k, qjets, out_u, \
+                                    ubar, qbar, part, part_stride, partk, partk_stride, row0, B);                      \
+  else hipLaunchKernelGGL((k_post_multi<NN, 3>), dim3(tiles), dim3(256), 0, st, prm, L, K, w4k, qjets, out_u, ubar,     \
+                          qbar, part, part_stride, partk, partk_stride, row0, B);
   QC_MLP_DISPATCH(L.n, CALL)
 #undef CALL
   return QC_OK;

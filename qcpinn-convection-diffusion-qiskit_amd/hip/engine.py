@@ -294,6 +294,61 @@ class SolverEngine:
                 "qc_reduce_rows")
         return d_flat
 
+    # ------------------------------------------------------------------ K outputs behind one shared network
+    def forward_multi(self, X: torch.Tensor, w4k: torch.Tensor):
+        """Six derivative channels of every output of a K-output model, [K, 6, B], from ONE pass of pre network,
+        circuit and hidden layer (qc_post_multi mode 4).  ``w4k`` = [K, H + 1] rows (W4[k], b4[k]); the W4 / b4 slots of
+        the flat vector are unused.  Returns (ujets, ajets, qjets)."""
+        X = self._X(X)
+        B, K = X.shape[0], int(w4k.shape[0])
+        st = _stream(self.device)
+        self.refresh_gates()
+        w4k = _need(w4k, self.device, "last-layer rows")
+        ajets = torch.empty(NCH, self.n, B, dtype=torch.float32, device=self.device)
+        L.check(self.lib.qc_pre_forward(X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
+                                        ajets.data_ptr(), B, NCH, st), "qc_pre_forward")
+        qjets = self.circuit.forward_jets(ajets)
+        uj = torch.empty(K, NCH, B, dtype=torch.float32, device=self.device)
+        L.check(self.lib.qc_post_multi(4, self.flat.data_ptr(), self.H, self.n, self.n_theta, K, w4k.data_ptr(),
+                                       qjets.data_ptr(), uj.data_ptr(), None, None, None, 0, None, 0, 0, B, st),
+                "qc_post_multi(forward)")
+        return uj, ajets, qjets
+
+    def backward_multi(self, X, ajets, qjets, w4k, ubar):
+        """Reverse of ``forward_multi``: ``ubar`` [K, 6, B] -> (d_flat (NP; zeros in the W4 / b4 slots), d_w4k [K, H + 1]),
+        one circuit adjoint sweep and one pre-network reverse pass for all K outputs."""
+        X = self._X(X)
+        B, K = X.shape[0], int(w4k.shape[0])
+        st = _stream(self.device)
+        rows = (B + 63) // 64
+        KW = K * (self.H + 1)
+        part = torch.empty(rows, self.NP, dtype=torch.float32, device=self.device)
+        partk = torch.empty(rows, KW, dtype=torch.float32, device=self.device)
+        qbar = torch.empty_like(qjets)
+        ub = _need(ubar.reshape(-1), self.device, "ubar")
+        if ub.numel() != K * NCH * B:
+            raise L.QcError("the cotangent must be a [K, 6, B] tensor")
+        w4k = _need(w4k, self.device, "last-layer rows")
+        L.check(self.lib.qc_post_multi(3, self.flat.data_ptr(), self.H, self.n, self.n_theta, K, w4k.data_ptr(),
+                                       qjets.data_ptr(), None, ub.data_ptr(), qbar.data_ptr(), part.data_ptr(), self.NP,
+                                       partk.data_ptr(), KW, 0, B, st), "qc_post_multi(backward)")
+        abar = torch.empty_like(ajets)
+        th = part.data_ptr() + 4 * self.theta_off
+        c = self.circuit
+        wp, wb = c.workspace(NCH, True, B)
+        cin = c._amp_fwd(ajets, NCH) if c.amplitude else ajets
+        L.check(self.lib.qc_backward_jets(c.handle, c.trig.data_ptr(), _ptr(c.umat), cin.data_ptr(), qbar.data_ptr(),
+                                          abar.data_ptr(), th, self.NP, 0, B, wp, wb, st), "qc_backward_jets")
+        if c.amplitude:
+            abar = c._amp_bwd(ajets, abar, NCH)
+        L.check(self.lib.qc_pre_backward(X.data_ptr(), self.flat.data_ptr(), self.H, self.n, self.n_theta,
+                                         abar.data_ptr(), part.data_ptr(), self.NP, 0, B, NCH, st), "qc_pre_backward")
+        d_flat = torch.empty(self.NP, dtype=torch.float32, device=self.device)
+        L.check(self.lib.qc_reduce_rows(part.data_ptr(), rows, self.NP, self.NP, d_flat.data_ptr(), st), "qc_reduce_rows")
+        d_w4k = torch.empty(KW, dtype=torch.float32, device=self.device)
+        L.check(self.lib.qc_reduce_rows(partk.data_ptr(), rows, KW, KW, d_w4k.data_ptr(), st), "qc_reduce_rows")
+        return d_flat, d_w4k.view(K, self.H + 1)
+
     # ------------------------------------------------------------------ fused training step
     def fused(self, B_res: int, n_ic: int, n_bc: int, opt: "OptimState", counts=None) -> "FusedStep":
         key = (B_res, n_ic, n_bc, id(opt), counts, self.problem, self.D, self.vx, self.vy, self.sigma, self.coeffs)

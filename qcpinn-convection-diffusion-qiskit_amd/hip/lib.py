@@ -26,7 +26,7 @@ EXPORTS = (
     "qc_circuit_workspace_bytes", "qc_circuit_workspace_bytes_batch", "qc_hbm_plan_describe", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_forward_jets_keep", "qc_backward_jets_kept", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
     "qc_sample_collocation", "qc_sample_collocation_faces", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
-    "qc_fused_step_stage", "qc_comm_unique_id", "qc_comm_create", "qc_comm_destroy", "qc_allreduce_grads",
+    "qc_fused_step_stage", "qc_post_multi", "qc_comm_unique_id", "qc_comm_create", "qc_comm_destroy", "qc_allreduce_grads",
 )
 
 
@@ -113,6 +113,7 @@ def load() -> C.CDLL:
     lib.qc_pre_backward.argtypes = [fp, fp, i32, i32, i32, fp, fp, i64, i64, i64, i32, vp]
     lib.qc_post.argtypes = [i32, fp, fp, i32, i32, i32, C.POINTER(QcPde), fp, fp, fp, fp, fp, fp, fp, i64, i64,
                             i64, i32, vp]
+    lib.qc_post_multi.argtypes = [i32, fp, i32, i32, i32, i32, fp, fp, fp, fp, fp, fp, i64, fp, i64, i64, i64, vp]
     lib.qc_reduce_rows.argtypes = [fp, i64, i64, i32, fp, vp]
     lib.qc_adam_step.argtypes = [fp, i32, fp, fp, fp, vp, C.POINTER(QcOptHyper), fp, i32, vp, i32, vp, vp]
     lib.qc_sample_collocation.argtypes = [fp, i64, i64, fp, i64, i64, i64, i64, C.c_uint64, C.c_uint64, vp]

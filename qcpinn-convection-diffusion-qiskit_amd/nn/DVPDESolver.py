@@ -98,6 +98,35 @@ class _JetsFn(torch.autograd.Function):
         return None, None, d_flat
 
 
+class _JetsAllFn(torch.autograd.Function):
+    """X (B,3), the flat vector of the SHARED parameters (single-output kernel layout, W4 / b4 slots unused) and the
+    last layer's rows w4k [K, H + 1] -> (B, K, 6): the six derivative channels of every output from ONE pass through pre
+    network, circuit and hidden layer (qc_post_multi); one adjoint sweep in the reverse pass.  Both parameter arguments
+    are assembled from the module's parameters by torch ops, so autograd carries the gradients on to them."""
+
+    @staticmethod
+    def forward(ctx, X, solver, flat, w4k):
+        eng = solver._jet_engine(X.device)
+        Xc = solver._pad_inputs(X.detach().to(torch.float32)).contiguous()
+        fl = flat.detach().to(torch.float32).contiguous()
+        wk = w4k.detach().to(torch.float32).contiguous()
+        eng.flat.copy_(fl)
+        uj, ajets, qjets = eng.forward_multi(Xc, wk)
+        ctx.eng = eng
+        ctx.save_for_backward(Xc, ajets, qjets, fl, wk)
+        return uj.permute(2, 0, 1).contiguous()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        Xc, ajets, qjets, fl, wk = ctx.saved_tensors
+        eng = ctx.eng
+        eng.flat.copy_(fl)
+        eng.refresh_gates()
+        d_flat, d_wk = eng.backward_multi(Xc, ajets, qjets, wk, g.to(torch.float32).permute(1, 2, 0).contiguous())
+        return None, None, d_flat, d_wk
+
+
 class _NoSecond(torch.autograd.Function):
     """Zero-valued guard of the input expansion (``DVPDESolver._forward_wrt_inputs``): contributes nothing to u and to its
     first derivatives, and makes every second derivative the kernels do NOT carry come out as NaN instead of a silent
@@ -283,6 +312,20 @@ class DVPDESolver(nn.Module):
                  post2.weight[out], post2.bias[out:out + 1]]
         parts += [p.reshape(-1) for p in self.quantum_layer.parameters()]
         return torch.cat([p.to(torch.float32) for p in parts])
+
+    def jets_all(self, X: torch.Tensor) -> torch.Tensor:
+        """(B, K, 6): (u_k, u_k,t, u_k,x, u_k,y, u_k,xx, u_k,yy) of every output k of a K-output model (K <= 4) from ONE
+        evaluation of pre network, circuit and hidden layer, and one adjoint sweep in the reverse pass (what the
+        Navier-Stokes operator of ``nn.pde`` uses for (u, v, p), reference nn/pde.py:2-27)."""
+        if X.dim() != 2 or X.shape[1] != self.input_dim:
+            raise ValueError(f"Expected points of shape (B, {self.input_dim}), got {tuple(X.shape)}")
+        if self.n_out > 4:
+            return torch.stack([self.jets(X, o) for o in range(self.n_out)], dim=1)
+        self._jet_engine(X.device)
+        post2 = self.postprocessor[2]
+        w4k = torch.cat([post2.weight, post2.bias[:, None]], dim=1).to(torch.float32)
+        flat = self._flat_for_output(0)          # the W4 / b4 slots are not read by the K-output post stage
+        return _JetsAllFn.apply(X, self, flat, w4k)
 
     def jets(self, X: torch.Tensor, out: int = 0) -> torch.Tensor:
         """(B, 6) = (u, u_t, u_x, u_y, u_xx, u_yy) of output ``out`` at X (B, input_dim), from the fused derivative-channel

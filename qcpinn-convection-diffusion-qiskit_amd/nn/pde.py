@@ -64,7 +64,8 @@ def navier_stokes_2D_operator(model, t, x, y, min_x=0, max_x=1):
         # a three-output DVPDESolver: the six derivative channels of u, v and p from the fused kernels, the
         # products of the momentum equations formed here (columns: value, t, x, y, xx, yy)
         X = torch.cat((t, x, y), 1)
-        U, V, P = jets(X, 0), jets(X, 1), jets(X, 2)
+        J = model.jets_all(X)                       # (B, 3, 6): one pass for the three outputs
+        U, V, P = J[:, 0], J[:, 1], J[:, 2]
         c = lambda J, k: J[:, k:k + 1]
         u, v = c(U, 0), c(V, 0)
         f_u = c(U, 1) + (u * c(U, 2) + v * c(U, 3)) + c(P, 2) / density - viscosity * (c(U, 4) + c(U, 5))

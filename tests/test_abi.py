@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.qc_version() == 3
+    assert lib.qc_version() == 4
     assert lib.qc_error_string(-1).decode() == "invalid argument"
 
 

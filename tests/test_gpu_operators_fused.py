@@ -114,6 +114,32 @@ def test_navier_stokes_on_fused_channels_matches_reference(gpu_device, tmp_path)
     assert f.shape == (X.shape[0], 3)
     J = [model.jets(X, o) for o in range(3)]
     assert max((f[:, o] - J[o][:, 0]).abs().max().item() for o in range(3)) < 1e-6
+    # the operator takes all three outputs from ONE pass (jets_all): one circuit evaluation and one adjoint sweep, where
+    # three single-output evaluations run three of each; same numbers
+    eng = model._jet_engine(X.device)
+    calls = {"fwd": 0, "bwd": 0}
+    fwd0, bwd0 = eng.circuit.forward_jets, eng.lib.qc_backward_jets
+
+    def count_fwd(a):
+        calls["fwd"] += 1
+        return fwd0(a)
+    eng.circuit.forward_jets = count_fwd
+    try:
+        JA = model.jets_all(X)
+        assert calls["fwd"] == 1
+        assert JA.shape == (X.shape[0], 3, 6)
+        assert max((JA[:, o] - J[o]).abs().max().item() for o in range(3)) < 2e-6
+        w = torch.randn_like(JA)
+        model.zero_grad()
+        (JA * w).sum().backward()
+        g_all = {k: v.grad.clone() for k, v in model.named_parameters()}
+        model.zero_grad()
+        sum((model.jets(X, o) * w[:, o]).sum() for o in range(3)).backward()
+        assert calls["fwd"] == 4
+        for k, v in model.named_parameters():
+            assert (v.grad - g_all[k]).abs().max().item() < 1e-5 * max(1.0, v.grad.abs().max().item()), k
+    finally:
+        eng.circuit.forward_jets = fwd0
     with pytest.raises(NotImplementedError):
         model.residual(X)
 

@@ -2,7 +2,7 @@
 # One GPU-box call that produces every rocprofv3 summary committed under profiles/ for a round.
 #   bash tools/collect_profiles.sh <round tag, e.g. r02>
 # Programs are started directly after "--" (no wrappers); counter passes are separate runs (tools/pmc_passes.sh).
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -14,11 +14,11 @@ import sys
 
 BENCH_KEYS = {  # bench.py kernel key -> kernel-name prefixes whose launches it covers
     "circuit_jets_bwd": ["k_jets_bwd<"], "circuit_jets_fwd": ["k_jets_fwd<"], "pre_bwd": ["k_pre_bwd<4, 6>"],
-    "pre_fwd": ["k_pre_fwd<4, 6>"], "post": ["k_post<4, 6, 2>", "k_post_wg<4, 6>"],
+    "pre_fwd": ["k_pre_fwd<4, 6>"], "post": ["k_post<4, 6, 2>", "k_post_wg<4, 6>", "k_post_fused<4, 6>"],
     "stage_circuit_bwd": ["k_circ_bwd_both<", "k_circ_bwd_both2<"], "stage_circuit_fwd": ["k_circ_fwd_both<"],
     "fold_rows": ["k_fold_rows"], "adam": ["k_adam_fast<true>"],
     "stage_pre_fwd": ["k_pre_fwd_both<"], "stage_pre_bwd": ["k_pre_bwd_both<"],
-    "stage_post": ["k_post_both<", "k_post_wg_both<"],
+    "stage_post": ["k_post_both<", "k_post_wg_both<", "k_post_fused_both<"],
 }
 
 
