@@ -983,7 +983,11 @@ struct RegLaunch {
     static const int stagger = [] { const char* e = getenv("QC_BWD2_STAGGER"); return e ? atoi(e) & 0xff : 0; }();
     if (!six && !pg->amplitude) {
       const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 192);
-      const size_t sh = ((size_t)3 * (2u << PG::N) * 64 + (size_t)4 * PG::N * 64 + (size_t)3 * pg->n_params) * sizeof(float);
+      // QC_BWD2_LDS_KB=k (diagnostic, A/B): k KB of unused dynamic LDS per block lower the blocks per CU, so that the grid
+      // runs in more than one round and the load phases of later blocks overlap the sweeps of earlier ones
+      static const size_t pad = [] { const char* e = getenv("QC_BWD2_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
+      const size_t sh = ((size_t)3 * (2u << PG::N) * 64 + (size_t)4 * PG::N * 64 + (size_t)3 * pg->n_params) * sizeof(float) + pad;
+      if (pad) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circ_bwd_both2<PG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(k_circ_bwd_both2<PG>, dim3(nr + nv), dim3(192), sh, st, pg->d_gates, trig, umat, pg->n_gates,
                          pg->n_params, ajets, qbar, abar, row0_r, Br, chi_store, angles, cot, d_angles, row0_v, Bv, part,
                          part_stride, qc_embed_flags(pg) | (stagger << 8), nv);
