@@ -536,12 +536,18 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
   // (two waves per SIMD do not cover an HBM round trip on their own: load, sweep, store, load ... left the memory
   // system idle during every sweep)
   constexpr bool PREF = BWD && LAST && din && NCH > 1;
-  qf2 nxt[PREF ? R : 1];
-  if constexpr (PREF) {
+  // the other adjoint stages read (chi, lam) of a channel: the same prefetch, twice the registers
+  constexpr bool PREF2 = BWD && !LAST && din && NCH > 1;
+  qf2 nxt[PREF || PREF2 ? R : 1], nxl[PREF2 ? R : 1];
+  if constexpr (PREF || PREF2) {
     using RD0 = H2sRound<PL, S, RF>;
     const int al0 = abase | h2s_deposit<typename RD0::LaneG, LBITS>(tid);
     const Cplx* g1 = chi_of(1);   // the sweep's first channel
     h2s_for<0, R>([&](auto Q) { nxt[Q] = *reinterpret_cast<const qf2*>(g1 + RD0::dr(Q) + al0); });
+    if constexpr (PREF2) {
+      const Cplx* l1 = lam_of(1);
+      h2s_for<0, R>([&](auto Q) { nxl[Q] = *reinterpret_cast<const qf2*>(l1 + RD0::dr(Q) + al0); });
+    }
   }
   struct LinRBP { static constexpr int at(int j) { return H2sStage<PL, S>::LBITS + j; } };
   struct LinLK { static constexpr int at(int k) { return k; } };
@@ -649,6 +655,9 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
                 if constexpr (PREF) x = c == 0 ? xz[q] : nxt[q];
                 else x = c == 0 ? xz[q] : *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
                 y = build_lam(c, lbase | RD::roff(q), x, xz[q], l0acc[q]);
+              } else if constexpr (PREF2) {
+                x = nxt[q];
+                y = nxl[q];
               } else {
                 x = *reinterpret_cast<const qf2*>(g + RD::dr(q) + alane);
                 y = *reinterpret_cast<const qf2*>(gl + RD::dr(q) + alane);
@@ -660,6 +669,15 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
               if (ci + 2 < NCH) {   // channels run 1, 2, ..., NCH - 1, 0: request channel ci + 2 now
                 const Cplx* gn = chi_of(ci + 2);
                 h2s_for<0, R>([&](auto Q) { nxt[Q] = *reinterpret_cast<const qf2*>(gn + RD::dr(Q) + alane); });
+              }
+            }
+            if constexpr (PREF2) {
+              if (ci + 1 < NCH) {   // next channel of the order 1, 2, ..., NCH - 1, 0
+                const int cn = ci + 2 < NCH ? ci + 2 : 0;
+                const Cplx* gn = chi_of(cn);
+                const Cplx* ln = lam_of(cn);
+                h2s_for<0, R>([&](auto Q) { nxt[Q] = *reinterpret_cast<const qf2*>(gn + RD::dr(Q) + alane); });
+                h2s_for<0, R>([&](auto Q) { nxl[Q] = *reinterpret_cast<const qf2*>(ln + RD::dr(Q) + alane); });
               }
             }
           }
