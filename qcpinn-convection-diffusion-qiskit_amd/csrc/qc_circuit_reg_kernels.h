@@ -702,6 +702,10 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
   constexpr int N = PG::N;
   constexpr int A2 = 2 << N;
   constexpr int NA = 1 << N;
+  // diagnostic (timing only, results wrong): bit 7 of the flags = every block reads the final states of tile 0, i.e.
+  // from cache - what the stage would take if its 56 MB of final states did not have to come from HBM / Infinity Cache
+  const bool same_tile = (amp & 0x80) != 0;
+  amp &= 0x7f;
   extern __shared__ float smem[];
   float* s_l0 = smem;                          // [3 waves][A2][64]: shares of lam_0
   float* s_t0 = s_l0 + 3 * A2 * 64;            // [2][N][64]: waves 1, 2: their channels' terms of abar[0]
@@ -733,7 +737,8 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
 
   const qf2* chi2 = reinterpret_cast<const qf2*>(chi_store);
   qf2* s_l02 = reinterpret_cast<qf2*>(s_l0);     // [3 waves][amplitude][64]
-  auto load_chi = [&](SV<N>& v, int c) { qc_chi_read<N>(v, chi_store, c, pcf()); };
+  auto pcs = [&]() { return same_tile ? (int64_t)(threadIdx.x & 63) : pcf(); };   // point index for final-state reads
+  auto load_chi = [&](SV<N>& v, int c) { qc_chi_read<N>(v, chi_store, c, pcs()); };
   auto dvec = [&](int c, QcPk<NA>& d) {
     float qb[N];
     const int64_t pq = pcf();
@@ -760,13 +765,13 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
         cl[1].a[k] *= qc_dup(da_[k]);
       }
     } else {                  // lam_x = D_x chi_0 + 2 D_xx chi_x (the same for y)
-      const int64_t pq = pcf();
+      const int64_t pqs = pcs();
 #pragma unroll
       for (int k = 0; k < NA; ++k)
-        mine[k * 64 + lane] = qc_pk_fma(qc_dup(da_[k]), cl[0].a[k], qc_dup(d[k]) * chi2[qc_chi_pair<A2>(chb, k, pq)]);
+        mine[k * 64 + lane] = qc_pk_fma(qc_dup(da_[k]), cl[0].a[k], qc_dup(d[k]) * chi2[qc_chi_pair<A2>(chb, k, pqs)]);
 #pragma unroll
       for (int k = 0; k < NA; ++k)
-        cl[1].a[k] = qc_pk_fma(qc_dup(2.f * d[k]), cl[0].a[k], qc_dup(da_[k]) * chi2[qc_chi_pair<A2>(0, k, pq)]);
+        cl[1].a[k] = qc_pk_fma(qc_dup(2.f * d[k]), cl[0].a[k], qc_dup(da_[k]) * chi2[qc_chi_pair<A2>(0, k, pqs)]);
     }
   }
   __syncthreads();   // shares of lam_0, s_cs, s_acc
@@ -788,9 +793,9 @@ __device__ __forceinline__ void k_jets_bwd2_body(const int64_t bid, const QcGate
           cl[1].a[k] = (s_l02[k * 64 + lane] + s_l02[(NA + k) * 64 + lane]) + s_l02[(2 * NA + k) * 64 + lane];
       } else {                // lam_xx = D_xx chi_0
         dvec(chb, d);
-        const int64_t pq = pcf();
+        const int64_t pqs = pcs();
 #pragma unroll
-        for (int k = 0; k < NA; ++k) cl[1].a[k] = qc_dup(d[k]) * chi2[qc_chi_pair<A2>(0, k, pq)];
+        for (int k = 0; k < NA; ++k) cl[1].a[k] = qc_dup(d[k]) * chi2[qc_chi_pair<A2>(0, k, pqs)];
       }
     }
     PG::bwd(cl, prog, trig, umat, n_gates, s_acc + wv * n_params, lane, amp >> 1);
@@ -890,7 +895,7 @@ __global__ void __launch_bounds__(192, 4) k_circ_bwd_both2(
     const float* __restrict__ ajets, const float* __restrict__ qbar, float* __restrict__ abar, int64_t row0_r, int64_t Br,
     const float* __restrict__ chi_store, const float* __restrict__ angles, const float* __restrict__ cot,
     float* __restrict__ d_angles, int64_t row0_v, int64_t Bv, float* __restrict__ part, int64_t part_stride, int amp, int n_val) {
-  const int stagger = amp >> 8;   // (launcher: bits 8.. of the flags word)
+  const int stagger = (amp >> 8) & 0xff;   // (launcher: bits 8.. of the flags word)
   amp &= 0xff;
   if ((int)blockIdx.x >= n_val)
     k_jets_bwd2_body<PG>(blockIdx.x - n_val, prog, trig, umat, n_gates, n_params, ajets, qbar, abar, part, part_stride, row0_r, Br,
@@ -985,12 +990,13 @@ struct RegLaunch {
       const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 192);
       // QC_BWD2_LDS_KB=k (diagnostic, A/B): k KB of unused dynamic LDS per block lower the blocks per CU, so that the grid
       // runs in more than one round and the load phases of later blocks overlap the sweeps of earlier ones
+      static const int same_tile = [] { const char* e = getenv("QC_BWD2_SAMETILE"); return (e && e[0] == '1') ? 0x80 : 0; }();
       static const size_t pad = [] { const char* e = getenv("QC_BWD2_LDS_KB"); return e ? (size_t)atoi(e) * 1024 : (size_t)0; }();
       const size_t sh = ((size_t)3 * (2u << PG::N) * 64 + (size_t)4 * PG::N * 64 + (size_t)3 * pg->n_params) * sizeof(float) + pad;
       if (pad) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_circ_bwd_both2<PG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       hipLaunchKernelGGL(k_circ_bwd_both2<PG>, dim3(nr + nv), dim3(192), sh, st, pg->d_gates, trig, umat, pg->n_gates,
                          pg->n_params, ajets, qbar, abar, row0_r, Br, chi_store, angles, cot, d_angles, row0_v, Bv, part,
-                         part_stride, qc_embed_flags(pg) | (stagger << 8), nv);
+                         part_stride, qc_embed_flags(pg) | (stagger << 8) | same_tile, nv);
       return QC_OK;
     }
     const int nr = qc_ceil_div(Br, 64), nv = qc_ceil_div(Bv, 384);
