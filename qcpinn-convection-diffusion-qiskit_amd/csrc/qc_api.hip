@@ -1,7 +1,6 @@
 // extern "C" entry points of libqcpinn_hip.so (declared in include/qcpinn_hip.h).
 // Argument checking happens here, once, on the host: the kernels assume validated shapes.
 #include "qc_internal.h"
-#include "qc_hbm_plan.h"
 #include "../../include/qcpinn_hip.h"
 
 #include <stdlib.h>
@@ -41,16 +40,10 @@ static inline bool force_wave() {
 static inline bool use_reg(int n) { return n >= 2 && n <= 5 && !force_wave(); }
 static inline bool use_wave(int n) { return n >= 1 && n <= 8; }
 static inline bool use_hbm(int n) { return n >= 9 && n <= 20; }
-// n >= 9, angle encoding: the round-structured plan (qc_circuit_hbm2.hip).  QC_HBM_V1=1 / QC_HBM_SIMPLE=1 keep the
-// round-1 kernels (one LDS round trip per gate / one pass per gate) as cross-checks.
-static inline bool use_h2(const qc_program* p) {
-  static const bool off = [] {
-    const char* a = getenv("QC_HBM_V1");
-    const char* b = getenv("QC_HBM_SIMPLE");
-    return (a && a[0] == '1') || (b && b[0] == '1');
-  }();
-  return p->h2 != nullptr && !p->amplitude && !off;
-}
+// n >= 9: the round-structured plan (qc_circuit_hbm2.hip; compile-time stage programs where one is registered).  The
+// round-1 kernels (one LDS round trip or one pass per gate) are gone since round 3; the plan interpreter
+// (QC_NO_STATIC=1) is the cross-check of the generated programs.
+static inline bool use_h2(const qc_program* p) { return p->h2 != nullptr; }
 // Budget of the resident per-tile stores: QC_HBM_KEEP_GB (default 96), never more than 85 % of the memory that is free
 // on the current device when a workspace is sized (a smaller or partly occupied GPU gets fewer resident tiles, not an
 // allocation failure).
@@ -163,7 +156,6 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   p->h_gates = h; p->d_gates = nullptr;
   p->static_id = (n_qubits >= 2 && n_qubits <= 5) ? qc_reg_match_static(p)
                  : ((n_qubits >= 6 && n_qubits <= 8) ? qc_wave_match_static(p) : -1);
-  p->hbm_plan = nullptr;
   p->h2 = nullptr;
   p->amplitude = 0;
   qc_find_diag_runs(p);
@@ -177,10 +169,8 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
     return hip_fail(e);
   }
   if (n_qubits >= 9 && n_qubits <= 20) {
-    p->hbm_plan = qc_hbm_plan_create(p);
-    p->h2 = p->hbm_plan ? qc_h2_create(p, (p->lead_rx && absorb_enabled()) ? 1 : 0) : nullptr;
-    if (!p->hbm_plan || !p->h2) {
-      if (p->hbm_plan) qc_hbm_plan_destroy((QcHbmPlan*)p->hbm_plan);
+    p->h2 = qc_h2_create(p, (p->lead_rx && absorb_enabled()) ? 1 : 0);
+    if (!p->h2) {
       (void)hipFree(p->d_gates);
       free(h);
       free(p);
@@ -193,7 +183,6 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
 
 int qc_program_destroy(qc_program* p) {
   if (!p) return QC_ERR_ARG;
-  if (p->hbm_plan) qc_hbm_plan_destroy((QcHbmPlan*)p->hbm_plan);
   if (p->h2) qc_h2_destroy(p->h2);
   if (p->d_gates) (void)hipFree(p->d_gates);
   free(p->h_gates);
@@ -204,12 +193,12 @@ int qc_program_destroy(qc_program* p) {
 int qc_program_set_encoding(qc_program* p, int amplitude) {
   if (!p || (amplitude != 0 && amplitude != 1)) return QC_ERR_ARG;
   if (amplitude && ((int64_t)1 << p->n_qubits) < p->n_qubits) return QC_ERR_ARG;
-  if (p->amplitude != amplitude && p->hbm_plan) {   // the staged plan folds the leading RX layer only for angle encoding
-    p->amplitude = amplitude;
-    QcHbmPlan* fresh = qc_hbm_plan_create(p);
-    if (!fresh) return QC_ERR_ALLOC;
-    qc_hbm_plan_destroy((QcHbmPlan*)p->hbm_plan);
-    p->hbm_plan = fresh;
+  if (p->amplitude != amplitude && p->h2) {   // the staged plan folds the leading RX layer only for angle encoding, and
+    p->amplitude = amplitude;                 // the generated programs embed angles
+    void* h2 = qc_h2_create(p, (p->lead_rx && !amplitude && absorb_enabled()) ? 1 : 0);
+    if (!h2) return QC_ERR_ALLOC;
+    qc_h2_destroy(p->h2);
+    p->h2 = h2;
   }
   p->amplitude = amplitude;
   return QC_OK;
@@ -246,13 +235,11 @@ static int check_circuit(const qc_program* p, const void* trig, const float* uma
 
 size_t qc_circuit_workspace_bytes(const qc_program* p, int nch, int backward) {
   if (!p || !use_hbm(p->n_qubits) || (nch != 1 && nch != 6)) return 0;
-  if (use_h2(p)) return qc_h2_bytes(p, p->h2, nch, backward != 0, 1);
-  return qc_hbm_workspace_bytes(p, nch, backward != 0);
+  return qc_h2_bytes(p, p->h2, nch, backward != 0, 1);
 }
 
 size_t qc_circuit_workspace_bytes_batch(const qc_program* p, int nch, int backward, int64_t B) {
   if (!p || B <= 0 || !use_hbm(p->n_qubits) || (nch != 1 && nch != 6)) return 0;
-  if (!use_h2(p)) return qc_hbm_workspace_bytes(p, nch, backward != 0);
   const int64_t tiles = qc_ceil_div(B, 64);
   const size_t all = qc_h2_bytes(p, p->h2, nch, backward != 0, tiles);
   if ((double)all <= hbm_budget_bytes()) return all;
@@ -261,7 +248,6 @@ size_t qc_circuit_workspace_bytes_batch(const qc_program* p, int nch, int backwa
 }
 
 static size_t round256(size_t v);
-static size_t hbm_base_bytes(const qc_program* p) { return (qc_hbm_workspace_bytes(p, 6, true) + 255) & ~(size_t)255; }
 // h2, fused step: residual tiles (6 channels) and value tiles (1 channel) each keep their own resident slots
 static size_t h2_res_bytes(const qc_program* p, int64_t B_res) {
   return B_res > 0 ? ((qc_h2_bytes(p, p->h2, 6, true, qc_ceil_div(B_res, 64)) + 255) & ~(size_t)255) : 0;
@@ -281,9 +267,6 @@ static size_t step_circuit_bytes(const qc_program* p, int64_t B_res, int64_t B_v
     const size_t some = (qc_h2_bytes(p, p->h2, 6, true, fit < 1 ? 1 : fit) + 255) & ~(size_t)255;
     return some > h2_min_bytes(p) ? some : h2_min_bytes(p);
   }
-  // round-1 kernels, n >= 9: the per-tile scratch, plus (when it fits the budget) one [chi | lam] slot per residual tile
-  // so the adjoint pass of the step starts from the forward pass's final states instead of recomputing them
-  if (use_hbm(p->n_qubits)) return hbm_base_bytes(p) + qc_hbm_keep_bytes(p, B_res);
   if (use_reg(p->n_qubits)) return qc_reg_chi_store_bytes(p, B_res);   // optional: enables the no-recompute adjoint
   if (use_wave(p->n_qubits)) return qc_wave_chi_store_bytes(p, B_res);   // same, compile-time programs at n = 6..8
   return 0;
@@ -315,8 +298,7 @@ int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, 
   if (rc) return rc;
   if (!angles || !expval) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = use_h2(p) ? qc_h2_forward(p, p->h2, (const QcTrig*)trig, umat, angles, expval, B, 1, ws, ws_bytes, false, (hipStream_t)stream)
-                   : qc_hbm_forward(p, (const QcTrig*)trig, umat, angles, expval, B, 1, ws, ws_bytes, (hipStream_t)stream);
+    rc = qc_h2_forward(p, p->h2, (const QcTrig*)trig, umat, angles, expval, B, 1, ws, ws_bytes, false, (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
@@ -332,10 +314,8 @@ int qc_backward_expval(const qc_program* p, const void* trig, const float* umat,
   if (rc) return rc;
   if (!angles || !cot || !d_angles || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = use_h2(p) ? qc_h2_backward(p, p->h2, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, 1, ws,
-                                    ws_bytes, false, (hipStream_t)stream)
-                   : qc_hbm_backward(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, 1, ws,
-                                     ws_bytes, (hipStream_t)stream);
+    rc = qc_h2_backward(p, p->h2, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, 1, ws,
+                                    ws_bytes, false, (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
@@ -352,8 +332,7 @@ int qc_forward_jets(const qc_program* p, const void* trig, const float* umat, co
   if (rc) return rc;
   if (!ajets || !qjets) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = use_h2(p) ? qc_h2_forward(p, p->h2, (const QcTrig*)trig, umat, ajets, qjets, B, 6, ws, ws_bytes, false, (hipStream_t)stream)
-                   : qc_hbm_forward(p, (const QcTrig*)trig, umat, ajets, qjets, B, 6, ws, ws_bytes, (hipStream_t)stream);
+    rc = qc_h2_forward(p, p->h2, (const QcTrig*)trig, umat, ajets, qjets, B, 6, ws, ws_bytes, false, (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)
@@ -369,10 +348,8 @@ int qc_backward_jets(const qc_program* p, const void* trig, const float* umat, c
   if (rc) return rc;
   if (!ajets || !qbar || !abar || !part || part_stride < p->n_params || row0 < 0) return QC_ERR_ARG;
   if (use_hbm(p->n_qubits)) {
-    rc = use_h2(p) ? qc_h2_backward(p, p->h2, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, 6, ws,
-                                    ws_bytes, false, (hipStream_t)stream)
-                   : qc_hbm_backward(p, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, 6, ws, ws_bytes,
-                                     (hipStream_t)stream);
+    rc = qc_h2_backward(p, p->h2, (const QcTrig*)trig, umat, ajets, qbar, abar, part, part_stride, row0, B, 6, ws,
+                                    ws_bytes, false, (hipStream_t)stream);
     return rc ? rc : after_launch();
   }
   rc = use_reg(p->n_qubits)

@@ -331,6 +331,11 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
     }
   };
   auto gen_amp = [&](int c, int l, int a) {   // local index l, global index a
+    if (A.amp) {   // amplitude encoding (nn/DVQuantumLayer.py:177-180): basis state a carries feature a (real), a < n
+      Cplx v = {0.f, 0.f};
+      if (a < n) v.re = A.ajets[((int64_t)c * n + a) * A.B + p];
+      return v;
+    }
     const int ord = c == 0 ? 0 : (c <= 3 ? 1 : 2);
     const float a0 = s_tabA[l & 63][0], a1 = s_tabA[l & 63][1], a2 = s_tabA[l & 63][2];
     const float b0 = s_tabB[l >> 6][0], b1 = s_tabB[l >> 6][1], b2 = s_tabB[l >> 6][2];
@@ -440,7 +445,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
   for (int ci = 0; ci < NCH; ++ci) {
     // backward: the value channel last (its cotangent needs every other channel's final state)
     const int c = BWD ? (ci + 1 < NCH ? ci + 1 : 0) : ci;
-    if (gen) {
+    if (gen && !A.amp) {
       gen_tables(c);
       H2_SYNC();
     }
@@ -735,6 +740,15 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           for (int q = 0; q < R; ++q) {
             g[tdp | lin_dep[q]] = t0[tsw ^ lin_sw[q]];
             gl[tdp | lin_dep[q]] = t1[tsw ^ lin_sw[q]];
+          }
+        } else if (A.amp) {
+          // amplitude encoding: the state is linear in the (real) initial amplitudes: abar[c][w] = 2 Re lam_c[w], w < n;
+          // basis state w sits in the tile whose non-local bits match it
+          for (int w = tid; w < n; w += NT) {
+            int nonloc = 0, l = 0;
+            for (int j = 0; j < sd.ngb; ++j) nonloc |= w & (1 << sd.gb[j]);
+            for (int j = 0; j < nloc; ++j) l |= ((w >> sd.lb[j]) & 1) << j;
+            if (nonloc == abase) A.abar[((int64_t)c * n + w) * A.B + p] = 2.f * t1[h2_swz<RB>(l)].re;
           }
         } else {
           // un-embed lam on the local wires (RX^dagger with this point's angles), then keep the amplitudes of weight <= 3
@@ -1132,7 +1146,7 @@ static std::vector<int> h2s_enumerate_rz_runs(const H2Plan& P) {
 void* qc_h2_create(const qc_program* pg, int absorb) {
   QcH2* h = new QcH2();
   H2Dev& D = h->dev;
-  const int sid = h2s_match(pg, absorb);
+  const int sid = pg->amplitude ? -1 : h2s_match(pg, absorb);   // (the generated programs embed angles)
   if (sid >= 0) {
     // the kernels were generated from the plan of the SAME planner at build time: trust them only if the plan built
     // now is identical, record by record
@@ -1331,9 +1345,14 @@ static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, c
   A.nx = D.nx;
   A.nc = D.nc;
   const int S = (int)P.stages.size();
+  const bool amp = pg->amplitude != 0;
+  A.amp = amp ? 1 : 0;
+  A.ajets = ajets;
+  A.abar = abar;
   if (do_fwd) {
-    hipLaunchKernelGGL((k_h2_wiredata<NCH>), dim3(qc_ceil_div(npts * n, 256)), dim3(256), 0, st, ajets, B, p_first, npts, n, w.wd, trig,
-                       P.absorb);
+    if (!amp)
+      hipLaunchKernelGGL((k_h2_wiredata<NCH>), dim3(qc_ceil_div(npts * n, 256)), dim3(256), 0, st, ajets, B, p_first, npts, n, w.wd,
+                         trig, P.absorb);
     for (int i = 0; i < S; ++i) {
       A.sd = P.stages[i];
       A.first = i == 0;
@@ -1367,7 +1386,7 @@ static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, c
                          part_stride, row0);
     }
   }
-  {
+  if (!amp) {
     const H2Stage& s0 = P.stages[0];
     const int ntau = 1 << s0.ngb;
     const size_t xb = sizeof(Cplx) * (size_t)ntau * D.nx;

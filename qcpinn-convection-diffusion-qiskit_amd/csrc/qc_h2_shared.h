@@ -65,6 +65,9 @@ struct H2Args {
   const int* sparse_idx;
   const int* wht_idx;
   int nx, nc;
+  int amp;               // amplitude encoding: the initial state is the feature jets themselves (plan interpreter only)
+  const float* ajets;    // amp: [nch][n][B] initial-amplitude jets (forward) ;  float* abar below receives their cotangents
+  float* abar;           // amp, backward first stage: [nch][n][B]
 };
 
 // Plan records are read with wave-uniform addresses; readfirstlane tells the compiler so (SGPRs instead of VGPRs for
