@@ -624,16 +624,11 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if ((rc = qc_pre_forward(d->X_res_dev, d->params_dev, H, n, d->n_theta, d->ajets_res_dev, d->B_res, 6, st))) return rc;
       // register family: keep the final states of the forward pass for the adjoint kernel of this step
       float* chi_store = (use_reg(n) && cws && cws_bytes >= qc_reg_chi_store_bytes(d->prog, d->B_res)) ? (float*)cws : nullptr;
-      // HBM family: per-tile kept-state store behind the per-tile scratch (present iff the caller's workspace has room)
       // lanes-as-amplitudes family, compile-time program: final states of the forward kernel kept for the adjoint kernel
       float* wave_store = nullptr;
       if (!use_reg(n) && use_wave(n) && cws && qc_wave_chi_store_bytes(d->prog, d->B_res) > 0 &&
           cws_bytes >= qc_wave_chi_store_bytes(d->prog, d->B_res))
         wave_store = (float*)cws;
-      void* hbm_store = nullptr;
-      if (use_hbm(n) && !h2 && cws && qc_hbm_keep_bytes(d->prog, d->B_res) > 0 &&
-          cws_bytes >= hbm_base_bytes(d->prog) + qc_hbm_keep_bytes(d->prog, d->B_res))
-        hbm_store = (char*)cws + hbm_base_bytes(d->prog);
       if (amp && (rc = qc_amp_forward(d->ajets_res_dev, u_res, n, d->B_res, 6, st))) return rc;
       const float* cin_res = amp ? u_res : d->ajets_res_dev;
       float* cout_res = amp ? ub_res : d->abar_res_dev;
@@ -647,10 +642,6 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       } else if (h2) {
         if ((rc = qc_h2_forward(d->prog, d->prog->h2, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, 6, h2_res_ws, h2_res_b,
                                 h2_resident, st))) return rc;
-        if ((rc = after_launch())) return rc;
-      } else if (hbm_store) {
-        if ((rc = qc_hbm_forward_keep(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, cws, hbm_base_bytes(d->prog),
-                                      hbm_store, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if ((rc = qc_forward_jets(d->prog, trig, d->umat_dev, cin_res, d->qjets_res_dev, d->B_res, cws, cws_bytes, st)))
         return rc;
@@ -669,10 +660,6 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       } else if (h2) {
         if ((rc = qc_h2_backward(d->prog, d->prog->h2, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,
                                  d->part_stride, 0, d->B_res, 6, h2_res_ws, h2_res_b, h2_resident, st))) return rc;
-        if ((rc = after_launch())) return rc;
-      } else if (hbm_store) {
-        if ((rc = qc_hbm_backward_kept(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res, d->part_dev + L.oTh,
-                                       d->part_stride, 0, d->B_res, cws, hbm_base_bytes(d->prog), hbm_store, st))) return rc;
         if ((rc = after_launch())) return rc;
       } else if ((rc = qc_backward_jets(d->prog, trig, d->umat_dev, cin_res, d->qbar_res_dev, cout_res,
                                         d->part_dev + L.oTh, d->part_stride, 0, d->B_res, cws, cws_bytes, st))) return rc;

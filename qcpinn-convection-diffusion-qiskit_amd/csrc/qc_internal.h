@@ -115,20 +115,7 @@ int qc_opt_adam(float* flat, int NP, float* prm, float* m, float* v, QcOptState*
 int qc_opt_prep_trig(const qc_program* pg, const float* theta, QcTrig* trig, hipStream_t);
 int qc_sample_launch(float* X_res, int64_t n_res, int64_t off_res, float* X_val, int64_t n_ic, int64_t off_ic,
                      int64_t n_bc, int64_t off_bc, int64_t bc_face_points, uint64_t seed, uint64_t step, hipStream_t);
-size_t qc_hbm_workspace_bytes(const qc_program* pg, int nch, bool backward);
-size_t qc_hbm_keep_slot_elems(const qc_program* pg);
-size_t qc_hbm_keep_bytes(const qc_program* pg, int64_t B);
-int qc_hbm_forward_keep(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
-                        int64_t B, void* ws, size_t ws_bytes, void* store, hipStream_t st);
-int qc_hbm_backward_kept(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets,
-                         const float* qbar, float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B,
-                         void* ws, size_t ws_bytes, void* store, hipStream_t st);
-int qc_hbm_forward(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, float* qjets,
-                   int64_t B, int nch, void* ws, size_t ws_bytes, hipStream_t);
-int qc_hbm_backward(const qc_program* pg, const QcTrig* trig, const float* umat, const float* ajets, const float* qbar,
-                    float* abar, float* part, int64_t part_stride, int64_t row0, int64_t B, int nch, void* ws,
-                    size_t ws_bytes, hipStream_t);
-// second-generation HBM family (qc_circuit_hbm2.hip): all tiles of a batch resident when the workspace allows
+// HBM family, n >= 9 (qc_circuit_hbm2.hip, qc_circuit_h2s_kernels.h): all tiles of a batch resident when the workspace allows
 void* qc_h2_create(const qc_program* pg, int absorb);
 void qc_h2_destroy(void* h2);
 int qc_h2_describe_gates(const QcGate* gates, int n_gates, int n_qubits, int absorb, int32_t* out, int cap);   // host only

@@ -40,8 +40,7 @@ struct qc_program {
   int static_id;    // index into the compile-time specialised programs, or -1
   QcGate* d_gates;  // device
   QcGate* h_gates;  // host copy
-  void* hbm_plan;   // QcHbmPlan* for n >= 9 (round-1 staged execution: amplitude encoding, cross-check hook), else null
-  void* h2;         // QcH2* for n >= 9: the round-structured plan of qc_hbm2_plan.h (angle encoding), else null
+  void* h2;         // QcH2* for n >= 9: the round-structured plan of qc_hbm2_plan.h, else null
   int amplitude;    // 1: amplitude encoding (initial state given directly), 0: RX angle embedding
   int lead_rx;      // 1: gates 0..n-1 are RX on wires 0..n-1 (cascade, cross_mesh): RX(p_w) RX(a_w) = RX(a_w + p_w)
   int n_diag_runs;  // n <= 5: runs of >= 2 consecutive diagonal gates (RZ / CRZ); each owns a 2^n phase table behind

@@ -170,19 +170,19 @@ def test_wave_family_agrees_with_oracle_at_small_n():
     assert " passed" in r.stdout
 
 
-def test_hbm_per_gate_path_agrees_with_staged_path():
-    """n >= 9: the staged plan (LDS tiles + fused diagonal tables) is the default; QC_HBM_SIMPLE=1 selects
-    the one-pass-per-gate form.  Both must pass the same golden / oracle checks (child process: the
-    switch is read once at library load)."""
+def test_plan_interpreter_agrees_with_the_oracle_like_the_generated_programs():
+    """n >= 9: gate programs with a generated compile-time stage program run it by default; QC_NO_STATIC=1 keeps the
+    run-time plan interpreter for them (and the run-time gate interpreters of the other families).  Both must pass
+    the same golden / oracle checks (child process: the switch is read once at library load)."""
     import subprocess
     import sys
-    env = dict(os.environ, QC_HBM_SIMPLE="1")
+    env = dict(os.environ, QC_NO_STATIC="1")
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "(golden and (n10 or n16)) or (expval_vjp and (cascade-9 or layered-10))"
+    sel = "(golden and (n10 or n16)) or (expval_vjp and (cascade-9 or layered-10 or cross_mesh-16))"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_circuit.py"), "-m", "gpu", "-q",
                         "-x", "-k", sel], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "4 passed" in r.stdout
+    assert "5 passed" in r.stdout
 
 
 AMP_CASES = [("cascade", 4, 1, 1, 70), ("layered", 5, 1, 1, 9), ("layered", 6, 1, 1, 5),

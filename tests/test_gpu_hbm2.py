@@ -74,14 +74,18 @@ def test_six_channels_and_cotangents_match_oracle(ans, n, L, seed, B, gpu_device
     assert np.abs(d_theta.cpu().double().numpy() - o["dp"].reshape(-1)).max() < 2e-5 * st
 
 
-@pytest.mark.parametrize("env", [{"QC_H2_RB": "4"}, {"QC_HBM_V1": "1"}, {"QC_NO_ABSORB": "1"}])
-def test_plan_variants_pass_the_same_checks(env):
-    """QC_H2_RB=4: sixteen amplitudes per thread, 256 threads (read once at load, hence the child process);
-    QC_HBM_V1=1: the round-1 kernels (one LDS round trip per gate); QC_NO_ABSORB=1: leading RX layer kept as gates."""
+@pytest.mark.parametrize("env,sel,count", [
+    ({"QC_H2_RB": "4"}, "value_channel and (cascade-14 or layered-13 or alternate-9 or layered-12)", 4),
+    ({"QC_NO_STATIC": "1"}, "(value_channel or six_channels) and (cross_mesh-12 or cross_mesh-13)", 4),
+    ({"QC_H2S_RB": "3"}, "(value_channel or six_channels) and cross_mesh-12", 2),
+    ({"QC_NO_ABSORB": "1"}, "value_channel and (cross_mesh-12 or cascade-14 or layered-13 or alternate-9)", 4)])
+def test_plan_variants_pass_the_same_checks(env, sel, count):
+    """QC_H2_RB=4: sixteen amplitudes per thread, 256 threads, in the plan interpreter (read once at load, hence the child
+    process); QC_NO_STATIC=1: the plan interpreter instead of the generated stage programs; QC_H2S_RB=3: the generated
+    program of the other tile geometry; QC_NO_ABSORB=1: leading RX layer kept as gates (no generated program matches)."""
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "value_channel and (cross_mesh-12 or cascade-14 or layered-13 or alternate-9)"
     files = [os.path.join(here, "test_gpu_hbm2.py")]
     r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k", sel], env=dict(os.environ, **env),
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "4 passed" in r.stdout
+    assert f"{count} passed" in r.stdout
