@@ -35,6 +35,7 @@ struct H2Dev {
   H2DiagGate* d_dgates = nullptr;
   int* d_sparse = nullptr;      // local indices of weight <= 3 (first stage's tile)
   int* d_rank = nullptr;        // inverse: local index -> position in d_sparse, or -1
+  int* d_postab = nullptr;      // k_h2_abar: positions of mu[k] in a point's [tau][rank] copy (pos1 | pos2 | pos3 | pair u | pair v)
   int* d_whtidx = nullptr;      // local masks of weight 0, 1, 2 (coefficient order of the table gradients)
   int* d_pslots = nullptr;      // per stage: parameter slot of in-round parametric gate pidx; offsets in pslot_off
   std::vector<int> pslot_off;
@@ -941,23 +942,38 @@ __global__ void __launch_bounds__(256) k_h2_fold_diag(const float* __restrict__ 
   }
 }
 
-// cotangents of the angle jets from the un-embedded, sparse lam of every channel (block = one point)
+// cotangents of the angle jets from the un-embedded, sparse lam of every channel (block = one point).
+// The positions of the needed amplitudes mu[k] (k of weight 1, 2, 3) inside the block's copy X[tau][rank] come from
+// tables built once per plan on the host (qc_h2_create): pos1[w] = E(w), pos2[w][v] = E(w) | E(v), pos3[w][pair (u < v)]
+// = E(u) ^ E(v) ^ E(w) - no per-lookup bit gathering - and the 120 pair terms of a wire are spread over the eight lanes
+// of its lane group (round 2 walked them on one lane per wire with 16 of 128 lanes busy: 40 k instructions per wave).
 template <int NCH>
 __global__ void __launch_bounds__(128) k_h2_abar(const Cplx* __restrict__ xi, Cplx* __restrict__ xwork, int64_t pt_stride,
                                                  int ntau, int nx, H2Stage sd, int n, const float* __restrict__ wd,
-                                                 const int* __restrict__ rank, int64_t B, int64_t p_first,
+                                                 const int* __restrict__ postab, int64_t B, int64_t p_first,
                                                  int64_t npts, float* __restrict__ abar, int use_lds) {
   extern __shared__ Cplx s_x[];          // [ntau][nx] when it fits, else the block works in xwork (global)
   __shared__ float s_buf[NCH][3][24];
+  __shared__ float s_da[24], s_dda[24];
   const int64_t pt = blockIdx.x;
   const int64_t p = p_first + pt;
   const int tid = threadIdx.x;
   const float* wdp = wd + (size_t)pt * n * 8;
-  const int nloc = sd.nloc;
+  const int npair = n * (n - 1) / 2;
+  const int* pos1 = postab;                       // [n]
+  const int* pos2 = postab + n;                   // [n][n]
+  const int* pos3 = postab + n + n * n;           // [n][npair]
+  const int* pu = pos3 + n * npair;               // [npair] u of pair
+  const int* pv = pu + npair;                     // [npair] v of pair
   for (int c = 0; c < NCH; ++c) {
     const Cplx* src = xi + ((size_t)c * pt_stride + pt) * ntau * nx;
     Cplx* X = use_lds ? s_x : xwork + (size_t)pt * ntau * nx;
     for (int i = tid; i < ntau * nx; i += 128) X[i] = src[i];
+    const int dsel = c == 0 ? 0 : (c <= 3 ? c - 1 : c - 3);
+    if (tid < n) {
+      s_da[tid] = c >= 1 ? wdp[(size_t)tid * 8 + 2 + dsel] : 0.f;
+      s_dda[tid] = c >= 4 ? wdp[(size_t)tid * 8 + 5 + (c - 4)] : 0.f;
+    }
     __syncthreads();
     // RX^dagger on the wires of the non-local bits: butterflies across tau
     for (int j = 0; j < sd.ngb; ++j) {
@@ -973,50 +989,50 @@ __global__ void __launch_bounds__(128) k_h2_abar(const Cplx* __restrict__ xi, Cp
       }
       __syncthreads();
     }
-    // mu[k] for a full index k of weight <= 3
-    auto mu = [&](int64_t k) {
-      int l = 0, g = 0;
-      for (int j = 0; j < nloc; ++j)
-        if ((k >> sd.lb[j]) & 1) l |= 1 << j;
-      for (int j = 0; j < sd.ngb; ++j)
-        if ((k >> sd.gb[j]) & 1) g |= 1 << j;
-      return X[(size_t)g * nx + rank[l]];
-    };
-    auto E = [&](int w) { return (int64_t)1 << (n - 1 - w); };
-    if (tid < n) {
-      const int w = tid;
-      const int dsel = c == 0 ? 0 : (c <= 3 ? c - 1 : c - 3);
-      auto da = [&](int v) { return wdp[(size_t)v * 8 + 2 + dsel]; };
-      auto dda = [&](int v) { return wdp[(size_t)v * 8 + 5 + (c - 4)]; };
-      const float ip0 = -mu(E(w)).im;
-      float ip1 = 0.f, ip2 = 0.f;
-      if (c >= 1) {
-        float acc = da(w) * mu(0).re;
-        for (int v = 0; v < n; ++v)
-          if (v != w) acc = fmaf(da(v), mu(E(w) | E(v)).re, acc);
-        ip1 = -0.5f * acc;
-      }
+    // wire w = lane group (8 lanes); its lanes share the sums over the other wires / pairs of wires
+    for (int w = tid >> 3; w < n; w += 16) {
+      const int sub = tid & 7;
+      const float mu0re = X[0].re;                       // mu[0]: index 0 is rank 0 of tau 0
+      const Cplx m1 = X[pos1[w]];
+      float acc1 = 0.f, accb = 0.f, acca = 0.f;
+      if (c >= 1)
+        for (int v = sub; v < n; v += 8)
+          if (v != w) acc1 = fmaf(s_da[v], X[pos2[w * n + v]].re, acc1);
       if (c >= 4) {
-        float S = 0.f;
-        for (int v = 0; v < n; ++v) S = fmaf(da(v), da(v), S);
-        float a = S * mu(E(w)).im;
-        float b = dda(w) * mu(0).re;
-        for (int u = 0; u < n; ++u) {
-          if (u != w) b = fmaf(dda(u), mu(E(w) | E(u)).re, b);
-          for (int v = u + 1; v < n; ++v) a = fmaf(2.f * da(u) * da(v), mu(E(u) ^ E(v) ^ E(w)).im, a);
-        }
-        ip2 = 0.25f * a - 0.5f * b;
+        for (int u = sub; u < n; u += 8)
+          if (u != w) accb = fmaf(s_dda[u], X[pos2[w * n + u]].re, accb);
+        for (int q = sub; q < npair; q += 8)
+          acca = fmaf(2.f * s_da[pu[q]] * s_da[pv[q]], X[pos3[w * npair + q]].im, acca);
       }
-      // slots as in the register family's tail (qc_circuit_reg_kernels.h): [0] own-order term, [1], [2] lower orders
-      if (c == 0) {
-        s_buf[c][0][w] = ip0;
-      } else if (c <= 3) {
-        s_buf[c][0][w] = ip1;
-        s_buf[c][1][w] = ip0;
-      } else {
-        s_buf[c][0][w] = ip2;
-        s_buf[c][1][w] = 2.f * ip1;
-        s_buf[c][2][w] = ip0;
+      // sum over the lane group's 8 lanes (quad_perm, quad_perm, row_half_mirror: lanes 0..7 of each half row)
+#define ABAR_SUM8_(x)                                                                                                         \
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));          \
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));          \
+      x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+      ABAR_SUM8_(acc1) ABAR_SUM8_(accb) ABAR_SUM8_(acca)
+#undef ABAR_SUM8_
+      if (sub == 0) {
+        const float ip0 = -m1.im;
+        float ip1 = 0.f, ip2 = 0.f;
+        if (c >= 1) ip1 = -0.5f * (s_da[w] * mu0re + acc1);
+        if (c >= 4) {
+          float S = 0.f;
+          for (int v = 0; v < n; ++v) S = fmaf(s_da[v], s_da[v], S);
+          const float a = S * m1.im + acca;
+          const float b = s_dda[w] * mu0re + accb;
+          ip2 = 0.25f * a - 0.5f * b;
+        }
+        // slots as in the register family's tail (qc_circuit_reg_kernels.h): [0] own-order term, [1], [2] lower orders
+        if (c == 0) {
+          s_buf[c][0][w] = ip0;
+        } else if (c <= 3) {
+          s_buf[c][0][w] = ip1;
+          s_buf[c][1][w] = ip0;
+        } else {
+          s_buf[c][0][w] = ip2;
+          s_buf[c][1][w] = 2.f * ip1;
+          s_buf[c][2][w] = ip0;
+        }
       }
     }
     __syncthreads();
@@ -1193,6 +1209,38 @@ void* qc_h2_create(const qc_program* pg, int absorb) {
   up(P.dgates.data(), sizeof(H2DiagGate) * P.dgates.size(), (void**)&D.d_dgates);
   up(P.sparse_idx.data(), sizeof(int) * P.sparse_idx.size(), (void**)&D.d_sparse);
   up(rank.data(), sizeof(int) * rank.size(), (void**)&D.d_rank);
+  {
+    // where the amplitude of full index k sits in a point's copy X[tau][rank] (first stage's tile geometry)
+    const H2Stage& s0 = P.stages[0];
+    const int n = pg->n_qubits, npair = n * (n - 1) / 2;
+    auto posof = [&](int64_t k) {
+      int l = 0, g = 0;
+      for (int j = 0; j < s0.nloc; ++j)
+        if ((k >> s0.lb[j]) & 1) l |= 1 << j;
+      for (int j = 0; j < s0.ngb; ++j)
+        if ((k >> s0.gb[j]) & 1) g |= 1 << j;
+      return g * D.nx + rank[l];
+    };
+    auto E = [&](int w) { return (int64_t)1 << (n - 1 - w); };
+    std::vector<int> tab((size_t)n + (size_t)n * n + (size_t)n * npair + 2 * (size_t)npair, 0);
+    int* pos1 = tab.data();
+    int* pos2 = pos1 + n;
+    int* pos3 = pos2 + n * n;
+    int* pu = pos3 + n * npair;
+    int* pv = pu + npair;
+    int q = 0;
+    for (int u = 0; u < n; ++u)
+      for (int v = u + 1; v < n; ++v, ++q) {
+        pu[q] = u;
+        pv[q] = v;
+      }
+    for (int w = 0; w < n; ++w) {
+      pos1[w] = posof(E(w));
+      for (int v = 0; v < n; ++v) pos2[w * n + v] = v == w ? 0 : posof(E(w) | E(v));
+      for (int qq = 0; qq < npair; ++qq) pos3[w * npair + qq] = posof(E(pu[qq]) ^ E(pv[qq]) ^ E(w));
+    }
+    up(tab.data(), sizeof(int) * tab.size(), (void**)&D.d_postab);
+  }
   up(wht.data(), sizeof(int) * wht.size(), (void**)&D.d_whtidx);
   up(pslots.data(), sizeof(int) * pslots.size(), (void**)&D.d_pslots);
   if (D.stat) {
@@ -1211,7 +1259,7 @@ void qc_h2_destroy(void* hp) {
   if (!hp) return;
   QcH2* h = (QcH2*)hp;
   H2Dev& D = h->dev;
-  void* ptrs[] = {D.d_rounds, D.d_gates, D.d_dgates, D.d_sparse, D.d_rank, D.d_whtidx, D.d_pslots, D.d_phdesc};
+  void* ptrs[] = {D.d_rounds, D.d_gates, D.d_dgates, D.d_sparse, D.d_rank, D.d_postab, D.d_whtidx, D.d_pslots, D.d_phdesc};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -1393,7 +1441,7 @@ static void h2_group(const qc_program* pg, const H2Dev& D, const QcTrig* trig, c
     const int use_lds = xb <= 64 * 1024 ? 1 : 0;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_h2_abar<NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     hipLaunchKernelGGL((k_h2_abar<NCH>), dim3((unsigned)npts), dim3(128), use_lds ? xb : 0, st, w.xi, w.xwork, npts64, ntau, D.nx, s0,
-                       n, w.wd, D.d_rank, B, p_first, npts, abar, use_lds);
+                       n, w.wd, D.d_postab, B, p_first, npts, abar, use_lds);
     if (P.absorb)
       hipLaunchKernelGGL(k_h2_absorb_grad, dim3(n, (unsigned)ntiles), dim3(64), 0, st, abar, B, p_first, pg->d_gates, part,
                          part_stride, row0);

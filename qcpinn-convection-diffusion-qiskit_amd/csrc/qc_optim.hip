@@ -170,15 +170,27 @@ __global__ void __launch_bounds__(64 * QC_RED_WAVES) k_fold_rows(float* __restri
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   const int RS = gridDim.y, rs = blockIdx.y;
+  // rows r, r + hop, r + 2 hop, ... of this wave: the first EIGHT are requested together (config 2 has ~7 per wave: one
+  // memory round trip instead of four dependent ones), then summed in the same fixed order as a two-chain loop
   float a0 = 0.f, a1 = 0.f;
   if (col < ncols) {
-    int64_t r = rs + (int64_t)RS * wave;
+    const int64_t r0 = rs + (int64_t)RS * wave;
     const int64_t hop = (int64_t)RS * QC_RED_WAVES;
-    for (; r + hop < rows; r += 2 * hop) {
-      a0 += part[r * stride + col];
-      a1 += part[(r + hop) * stride + col];
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t r = r0 + k * hop;
+      v[k] = r < rows ? part[r * stride + col] : 0.f;
     }
-    if (r < rows) a0 += part[r * stride + col];
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+      a0 += v[k];
+      a1 += v[k + 1];
+    }
+    for (int64_t r = r0 + 8 * hop; r < rows; r += 2 * hop) {
+      a0 += part[r * stride + col];
+      if (r + hop < rows) a1 += part[(r + hop) * stride + col];
+    }
   }
   s[wave][lane] = a0 + a1;
   __syncthreads();
@@ -220,16 +232,14 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
     }
     if (i < NP + 3) {
       if constexpr (FOLD) {
+        // all (<= 32) folded rows requested together: one memory round trip, then the same left-to-right sum
         float t = 0.f;
-        int q = 0;
-        for (; q + 8 <= RS; q += 8) {
-          float x[8];
+        float x[32];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x[j] = part[(int64_t)(q + j) * stride + i];
+        for (int j = 0; j < 32; ++j) x[j] = j < RS ? part[(int64_t)j * stride + i] : 0.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) t += x[j];
-        }
-        for (; q < RS; ++q) t += part[(int64_t)q * stride + i];
+        for (int j = 0; j < 32; ++j) t += x[j];       // (rows >= RS add +0.f: the sum is unchanged)
+        for (int q = 32; q < RS; ++q) t += part[(int64_t)q * stride + i];
         g[k] = t;
       } else {
         g[k] = a.flat[i];
