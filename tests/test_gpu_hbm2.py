@@ -78,14 +78,15 @@ def test_six_channels_and_cotangents_match_oracle(ans, n, L, seed, B, gpu_device
     ({"QC_H2_RB": "4"}, "value_channel and (cascade-14 or layered-13 or alternate-9 or layered-12)", 4),
     ({"QC_NO_STATIC": "1"}, "(value_channel or six_channels) and (cross_mesh-12 or cross_mesh-13)", 4),
     ({"QC_H2S_RB": "3"}, "(value_channel or six_channels) and cross_mesh-12", 2),
-    ({"QC_NO_ABSORB": "1"}, "value_channel and (cross_mesh-12 or cascade-14 or layered-13 or alternate-9)", 4)])
+    ({"QC_NO_ABSORB": "1"}, "value_channel and (cross_mesh-12 or cascade-14 or layered-13 or alternate-9)", 4)],
+    ids=["interp_rb4", "no_static", "static_rb3", "no_absorb"])   # (ids without the selection text: the child must not select this test)
 def test_plan_variants_pass_the_same_checks(env, sel, count):
     """QC_H2_RB=4: sixteen amplitudes per thread, 256 threads, in the plan interpreter (read once at load, hence the child
     process); QC_NO_STATIC=1: the plan interpreter instead of the generated stage programs; QC_H2S_RB=3: the generated
     program of the other tile geometry; QC_NO_ABSORB=1: leading RX layer kept as gates (no generated program matches)."""
     here = os.path.dirname(os.path.abspath(__file__))
     files = [os.path.join(here, "test_gpu_hbm2.py")]
-    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k", sel], env=dict(os.environ, **env),
-                       capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([sys.executable, "-m", "pytest", *files, "-m", "gpu", "-q", "-x", "-k", f"({sel}) and not plan_variants"],
+                       env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert f"{count} passed" in r.stdout
