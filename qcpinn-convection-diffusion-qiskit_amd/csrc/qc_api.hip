@@ -1,6 +1,7 @@
 // extern "C" entry points of libqcpinn_hip.so (declared in include/qcpinn_hip.h).
 // Argument checking happens here, once, on the host: the kernels assume validated shapes.
 #include "qc_internal.h"
+#include "qc_wave_sched.h"
 #include "../../include/qcpinn_hip.h"
 
 #include <stdlib.h>
@@ -162,8 +163,26 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
   p->lead_rx = detect_lead_rx(h, n_gates, n_qubits);
   hipError_t e = hipMalloc((void**)&p->d_gates, sizeof(QcGate) * n_gates);
   if (e == hipSuccess) e = hipMemcpy(p->d_gates, h, sizeof(QcGate) * n_gates, hipMemcpyHostToDevice);
+#ifndef QC_WAVE_NO_RUNS
+  if (e == hipSuccess && n_qubits >= 6 && n_qubits <= 8 && p->static_id >= 0) {
+    // the compile-time program of this gate list multiplies by one phase table per RZ run: the same schedule, evaluated
+    // here, names the gates behind each table for the kernels that (re)build the trig buffer
+    const QcWaveSched ws = qc_wave_schedule(h, n_gates, n_qubits);
+    if (ws.n_runs > 0) {
+      const int ne = ws.run_off[ws.n_runs];
+      e = hipMalloc((void**)&p->d_diag_list, sizeof(int) * ne);
+      if (e == hipSuccess) e = hipMemcpy(p->d_diag_list, ws.entry, sizeof(int) * ne, hipMemcpyHostToDevice);
+      p->n_diag_runs = ws.n_runs;
+      for (int r = 0; r < ws.n_runs; ++r) {
+        p->diag_g0[r] = ws.run_off[r];
+        p->diag_g1[r] = ws.run_off[r + 1];
+      }
+    }
+  }
+#endif
   if (e != hipSuccess) {
     if (p->d_gates) (void)hipFree(p->d_gates);
+    if (p->d_diag_list) (void)hipFree(p->d_diag_list);
     free(h);
     free(p);
     return hip_fail(e);
@@ -172,6 +191,7 @@ int qc_program_create(const int32_t* rows, int n_gates, int n_qubits, int n_para
     p->h2 = qc_h2_create(p, (p->lead_rx && absorb_enabled()) ? 1 : 0);
     if (!p->h2) {
       (void)hipFree(p->d_gates);
+      if (p->d_diag_list) (void)hipFree(p->d_diag_list);
       free(h);
       free(p);
       return QC_ERR_ALLOC;
@@ -185,6 +205,7 @@ int qc_program_destroy(qc_program* p) {
   if (!p) return QC_ERR_ARG;
   if (p->h2) qc_h2_destroy(p->h2);
   if (p->d_gates) (void)hipFree(p->d_gates);
+  if (p->d_diag_list) (void)hipFree(p->d_diag_list);
   free(p->h_gates);
   free(p);
   return QC_OK;

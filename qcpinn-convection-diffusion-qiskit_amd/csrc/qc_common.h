@@ -14,7 +14,7 @@
 static inline int qc_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------ wave-level reductions
-// ---- fused diagonal runs (register family, n <= 5)
+// ---- fused diagonal runs (register family, n <= 5; compile-time programs of the wave family: qc_wave_sched.h)
 // A run of >= 2 consecutive RZ / CRZ gates is one element-wise multiply by D[k] = prod_g phase_g(k), phase =
 // c -+ i s by the target bit (CRZ: only where the control bit is set).  The tables live behind the n_gates per-gate
 // entries of the trig buffer ({c, s} = {Re D, Im D}), run r at [n_gates + r * 2^n, ...), and are rebuilt with it.
@@ -23,11 +23,13 @@ __host__ __device__ inline bool qc_is_diag_op(int op) { return op == 2 /* QC_RZ 
 struct QcDiagRuns {   // kernel-argument copy of qc_program's run list
   int n;
   int g0[QC_MAX_DIAG_RUNS], g1[QC_MAX_DIAG_RUNS];
+  const int* list;    // null: run r = gates g0[r] .. g1[r]-1; else gates list[g0[r]] .. list[g1[r]-1] (qc_wave_sched.h)
 };
 
 // fills pg->n_diag_runs / diag_g0 / diag_g1 (host); more than QC_MAX_DIAG_RUNS runs: none is fused
 inline void qc_find_diag_runs(qc_program* pg) {
   pg->n_diag_runs = 0;
+  pg->d_diag_list = nullptr;
   if (pg->n_qubits > 5) return;
   for (int g = 0; g < pg->n_gates;) {
     if (!qc_is_diag_op(pg->h_gates[g].op)) { ++g; continue; }
@@ -45,6 +47,7 @@ inline void qc_find_diag_runs(qc_program* pg) {
 inline QcDiagRuns qc_diag_runs_of(const qc_program* pg) {
   QcDiagRuns r;
   r.n = pg ? pg->n_diag_runs : 0;
+  r.list = pg ? pg->d_diag_list : nullptr;
   for (int i = 0; i < QC_MAX_DIAG_RUNS; ++i) {
     r.g0[i] = (pg && i < r.n) ? pg->diag_g0[i] : 0;
     r.g1[i] = (pg && i < r.n) ? pg->diag_g1[i] : 0;
@@ -57,11 +60,12 @@ inline QcDiagRuns qc_diag_runs_of(const qc_program* pg) {
 __device__ inline void qc_fill_diag_tables(const QcGate* __restrict__ prog, int n_gates, int n_qubits,
                                            QcTrig* __restrict__ trig, int tid, const QcDiagRuns& runs,
                                            const float* cs = nullptr) {
-  if (n_qubits > 5 || tid >= (1 << n_qubits)) return;
+  if (runs.n == 0 || n_qubits > 8 || tid >= (1 << n_qubits)) return;
   const int k = tid;
   for (int r = 0; r < runs.n; ++r) {
     float dr = 1.f, di = 0.f;
-    for (int h = runs.g0[r]; h < runs.g1[r]; ++h) {
+    for (int hh = runs.g0[r]; hh < runs.g1[r]; ++hh) {
+      const int h = runs.list ? runs.list[hh] : hh;
       const QcGate gt = prog[h];
       const bool ctl = gt.op == 6;
       const int tb = ctl ? gt.bb : gt.ba;

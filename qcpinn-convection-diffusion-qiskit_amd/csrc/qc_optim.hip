@@ -290,12 +290,12 @@ __global__ void __launch_bounds__(1024) k_adam_fast(QcAdamArgs a, const float* _
         sincosf(0.5f * tr.th, &tr.s, &tr.c);
       }
       a.trig[gi] = tr;
-      if (a.n_qubits <= 5) {          // (cos, sin) of every gate also to LDS, for the diagonal-run tables below
+      if (a.runs.n > 0) {             // (cos, sin) of every gate also to LDS, for the diagonal-run tables below
         s_cs[2 * gi] = tr.c;
         s_cs[2 * gi + 1] = tr.s;
       }
     }
-  if (a.prog != nullptr && a.n_qubits <= 5) {
+  if (a.prog != nullptr && a.runs.n > 0) {
     __syncthreads();
     qc_fill_diag_tables(a.prog, a.n_gates, a.n_qubits, a.trig, tid, a.runs, s_cs);
   }

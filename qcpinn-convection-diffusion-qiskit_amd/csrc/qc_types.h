@@ -43,7 +43,9 @@ struct qc_program {
   void* h2;         // QcH2* for n >= 9: the round-structured plan of qc_hbm2_plan.h, else null
   int amplitude;    // 1: amplitude encoding (initial state given directly), 0: RX angle embedding
   int lead_rx;      // 1: gates 0..n-1 are RX on wires 0..n-1 (cascade, cross_mesh): RX(p_w) RX(a_w) = RX(a_w + p_w)
-  int n_diag_runs;  // n <= 5: runs of >= 2 consecutive diagonal gates (RZ / CRZ); each owns a 2^n phase table behind
-                    // the per-gate entries of the trig buffer (see qc_fill_diag_tables)
-  int diag_g0[QC_MAX_DIAG_RUNS], diag_g1[QC_MAX_DIAG_RUNS];   // gate ranges [g0, g1) of those runs
+  int n_diag_runs;  // n <= 5: runs of >= 2 consecutive diagonal gates (RZ / CRZ); n = 6..8 with a compile-time program:
+                    // the RZ runs of qc_wave_sched.h.  Each owns a 2^n phase table behind the per-gate entries of the
+                    // trig buffer (see qc_fill_diag_tables)
+  int diag_g0[QC_MAX_DIAG_RUNS], diag_g1[QC_MAX_DIAG_RUNS];   // gate ranges [g0, g1) of those runs, or (d_diag_list set)
+  int* d_diag_list;                                           // ranges of this device list of gate indices
 };

@@ -34,6 +34,15 @@ constexpr bool qc_ws_blocks(const G& g, int b) {
   }
 }
 
+// every gate a gate, in program order
+constexpr QcWaveSched qc_wave_plain_schedule(int n_gates) {
+  QcWaveSched s{};
+  s.ok = n_gates <= QC_WS_MAX_ITEMS;
+  for (int g = 0; g < n_gates && g < QC_WS_MAX_ITEMS; ++g) s.item[g] = g;
+  s.n_items = n_gates < QC_WS_MAX_ITEMS ? n_gates : QC_WS_MAX_ITEMS;
+  return s;
+}
+
 template <class G>
 constexpr QcWaveSched qc_wave_schedule(const G* gates, int n_gates, int n_qubits) {
   QcWaveSched s{};
@@ -50,11 +59,7 @@ constexpr QcWaveSched qc_wave_schedule(const G* gates, int n_gates, int n_qubits
   int fl[32] = {};                // floating RZ gates (not yet emitted), any number per bit, in program order
   int n_fl = 0;
   unsigned fl_bits = 0;
-  if (!s.ok) {
-    for (int g = 0; g < n_gates && g < QC_WS_MAX_ITEMS; ++g) s.item[g] = g;
-    s.n_items = n_gates < QC_WS_MAX_ITEMS ? n_gates : QC_WS_MAX_ITEMS;
-    return s;
-  }
+  if (!s.ok) return qc_wave_plain_schedule(n_gates);
   for (int g = 0; g < n_gates; ++g) run_of[g] = -1;
   auto flush = [&]() {
     if (n_fl == 0) return;
