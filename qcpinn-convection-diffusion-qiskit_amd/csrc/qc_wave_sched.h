@@ -1,11 +1,13 @@
 // Diagonal-run schedule of a gate program for the compile-time programs of the lanes-as-amplitudes family (n = 6..8).
 //
-// RZ gates commute with every gate that does not act on their wire and with everything diagonal on it (RZ, CRZ, the
-// control of CNOT / CRX).  The schedule moves each RZ as far as that allows and collects the ones that meet into runs;
+// RZ and CRZ gates commute with every gate that does not act on their wires and with everything diagonal on them (RZ,
+// CRZ, the control of CNOT / CRX).  The schedule moves each of them as far as that allows and collects the ones that meet into runs;
 // a run is ONE element-wise multiply by a 2^n phase table (built with the trig table, qc_fill_diag_tables) instead
 // of one 2x2 update per gate, and its gradients come from one pass over t[k] = Im(conj(lam_k) chi_k).  The reference's
 // layered ansatz (nn/DVQuantumLayer.py:184-212: RZ RX per wire | CNOT ring | RX RZ per wire, per layer) turns into
-// [run | RX x n | ring | RX x n | run of 2n | RX x n | ring | RX x n | run]: 3 table multiplies for 4n RZ gates.
+// [run | RX x n | ring | RX x n | run of 2n | RX x n | ring | RX x n | run]: 3 table multiplies for 4n RZ gates; the
+// cross-mesh ansatz (:348-371: RX, RZ per wire | CRZ between every ordered pair | RX, RZ per wire) into
+// [RX x n | run of n + n(n-1) | RX x n | run of n].
 //
 // One constexpr function serves both sides: the generated kernels evaluate it at compile time on their gate list,
 // the host evaluates it at program creation on the same list to know which gates feed which table.  Plain C++.
@@ -19,7 +21,7 @@ struct QcWaveSched {
   int item[QC_WS_MAX_ITEMS];        // >= 0: gate index (its own trig entry); < 0: -(run + 1)
   int n_runs;
   int run_off[QC_MAX_DIAG_RUNS + 1];
-  int entry[QC_WS_MAX_ITEMS];       // gate indices of the runs' RZ gates, run r at [run_off[r], run_off[r + 1])
+  int entry[QC_WS_MAX_ITEMS];       // gate indices of the runs' RZ / CRZ gates, run r at [run_off[r], run_off[r + 1])
   bool ok;                          // false: program too long for the fixed arrays (no run is formed)
 };
 
@@ -56,7 +58,7 @@ constexpr QcWaveSched qc_wave_schedule(const G* gates, int n_gates, int n_qubits
   int n_ids = 0;
   int last_run = -1;              // the most recently emitted run; `blocked` = bits acted on non-diagonally since
   unsigned blocked = 0;
-  int fl[32] = {};                // floating RZ gates (not yet emitted), any number per bit, in program order
+  int fl[QC_WS_MAX_ITEMS] = {};   // floating diagonal gates (not yet emitted), any number per bit, in program order
   int n_fl = 0;
   unsigned fl_bits = 0;
   if (!s.ok) return qc_wave_plain_schedule(n_gates);
@@ -74,17 +76,14 @@ constexpr QcWaveSched qc_wave_schedule(const G* gates, int n_gates, int n_qubits
   };
   for (int g = 0; g < n_gates; ++g) {
     const G& gt = gates[g];
-    if (gt.op == QC_RZ && gt.slot >= 0) {
-      if (last_run >= 0 && !((blocked >> gt.ba) & 1u) && !((fl_bits >> gt.ba) & 1u)) {
+    if ((gt.op == QC_RZ || gt.op == QC_CRZ) && gt.slot >= 0) {
+      const unsigned m = (1u << gt.ba) | (gt.op == QC_CRZ ? (1u << gt.bb) : 0u);
+      if (last_run >= 0 && !(blocked & m)) {
         run_of[g] = last_run;                              // moves back to the emitted run
         ++run_size[last_run];
-      } else if (n_fl < 32) {
-        fl[n_fl++] = g;                                    // floats forward
-        fl_bits |= 1u << gt.ba;
       } else {
-        flush();
-        fl[n_fl++] = g;
-        fl_bits |= 1u << gt.ba;
+        fl[n_fl++] = g;                                    // floats forward
+        fl_bits |= m;
       }
       continue;
     }
