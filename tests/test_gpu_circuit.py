@@ -132,6 +132,7 @@ JETS_CASES = [
     ("cascade", 7, 1, 1, 1),   # no generated static program: the run-time interpreter of the wave family
     ("cascade", 9, 1, 1, 1),
     ("layered", 8, 2, 1, 3), ("layered", 10, 1, 1, 2),   # (the float64 oracle's jets cost ~1 min per case: cached)
+    ("cross_mesh", 8, 1, 1, 2),   # compile-time program whose 56 CRZ + 8 RZ gates are ONE phase-table run (qc_wave_sched.h)
 ]
 
 

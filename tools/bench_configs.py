@@ -65,7 +65,11 @@ if __name__ == "__main__":
     ap.add_argument("--skip5", action="store_true")
     ap.add_argument("--steps5", type=int, default=2)
     ap.add_argument("--steps3", type=int, default=5)
+    ap.add_argument("--extra", default="", help="one more workload: ansatz,n_qubits,layers,batch (e.g. cross_mesh,8,1,131072)")
     a = ap.parse_args()
+    if a.extra:
+        ans, n, L, B = a.extra.split(",")
+        run(f"{ans} n={n} L={L}", int(n), ans, int(L), int(B), steps=a.steps3, warmup=2)
     if not a.skip3:
         run("config 3", 8, "layered", 2, a.b3, steps=a.steps3, warmup=2 if a.steps3 > 1 else 1)
     if not a.skip5:
