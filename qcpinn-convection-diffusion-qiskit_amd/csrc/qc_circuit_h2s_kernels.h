@@ -347,6 +347,12 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
   Cplx* slot = A.store + (size_t)tile64 * A.slot_elems;
   auto chi_of = [&](int c) { return slot + ((size_t)c * 64 + t) * N; };
   auto lam_of = [&](int c) { return slot + ((size_t)(NCH + c) * 64 + t) * N; };
+  // Final states of a multi-stage plan live in the LAM half of the slot (free during the forward pass): the chi half keeps
+  // the state before the last stage, which is what the adjoint of the stage before it reads - the last adjoint stage
+  // overwrites the final states with its cotangents in place and does not write an un-computed copy of chi back
+  // (one state transfer of eight less per channel).
+  constexpr bool FINL = LAST && !FIRST;
+  auto fin_of = [&](int c) { return FINL ? lam_of(c) : chi_of(c); };
 
   // registers that live across the channel loop
   qf2 x0[!BWD && LAST ? R : 1];       // forward, last stage: final value-channel tile
@@ -522,7 +528,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
   // the tile five times from HBM)
   qf2 xz[BWD && LAST ? R : 1];
   if constexpr (BWD && LAST) {
-    const Cplx* g0 = chi_of(0);
+    const Cplx* g0 = fin_of(0);
     if constexpr (din) {
       using RD0 = H2sRound<PL, S, RF>;
       const int al0 = abase | h2s_deposit<typename RD0::LaneG, LBITS>(tid);
@@ -542,7 +548,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
   if constexpr (PREF || PREF2) {
     using RD0 = H2sRound<PL, S, RF>;
     const int al0 = abase | h2s_deposit<typename RD0::LaneG, LBITS>(tid);
-    const Cplx* g1 = chi_of(1);   // the sweep's first channel
+    const Cplx* g1 = PREF ? fin_of(1) : chi_of(1);   // the sweep's first channel
     h2s_for<0, R>([&](auto Q) { nxt[Q] = *reinterpret_cast<const qf2*>(g1 + RD0::dr(Q) + al0); });
     if constexpr (PREF2) {
       const Cplx* l1 = lam_of(1);
@@ -564,7 +570,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
     if constexpr (!din) {
       const int tg = ftid();
       const int tsw = h2_swz<RB>(tg), tdp = abase | h2s_deposit<typename ST::LinG, LBITS>(tg);
-      const Cplx* g = chi_of(c);
+      const Cplx* g = (BWD && LAST) ? fin_of(c) : chi_of(c);
       if constexpr (!BWD) {
         const qf2 bp = gen ? base_phase(tdp) : (qf2){0.f, 0.f};
         h2s_for<0, R>([&](auto Q) {
@@ -632,7 +638,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
         constexpr bool first_r = ri == 0, last_r = ri == NR - 1;
         SV<RB> v[KV];
         if constexpr (first_r && din) {
-          const Cplx* g = chi_of(c);
+          const Cplx* g = (BWD && LAST) ? fin_of(c) : chi_of(c);
           if constexpr (!BWD) {
             if constexpr (gen) {
               const qf2 bp = base_phase(alane);
@@ -667,7 +673,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
             });
             if constexpr (PREF) {
               if (ci + 2 < NCH) {   // channels run 1, 2, ..., NCH - 1, 0: request channel ci + 2 now
-                const Cplx* gn = chi_of(ci + 2);
+                const Cplx* gn = fin_of(ci + 2);
                 h2s_for<0, R>([&](auto Q) { nxt[Q] = *reinterpret_cast<const qf2*>(gn + RD::dr(Q) + alane); });
               }
             }
@@ -737,7 +743,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
               expval(c, fin, RBP{}, typename RD::LaneL{});
             }
             if (!LAST || A.keep_final) {
-              Cplx* g = chi_of(c);
+              Cplx* g = LAST ? fin_of(c) : chi_of(c);
               h2s_for<0, R>([&](auto Q) {
                 constexpr int q = Q;
                 *reinterpret_cast<qf2*>(g + RD::dr(q) + alane) = v[0].a[q];
@@ -748,7 +754,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
             Cplx* gl = lam_of(c);
             h2s_for<0, R>([&](auto Q) {
               constexpr int q = Q;
-              *reinterpret_cast<qf2*>(g + RD::dr(q) + alane) = v[0].a[q];
+              if constexpr (!FINL) *reinterpret_cast<qf2*>(g + RD::dr(q) + alane) = v[0].a[q];   // (FINL: the chi half has it)
               *reinterpret_cast<qf2*>(gl + RD::dr(q) + alane) = v[1].a[q];
             });
           }
@@ -782,7 +788,7 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
           h2s_for<0, R>([&](auto Q) { fin[Q] = *reinterpret_cast<const qf2*>(t0 + (tsw ^ ST::lin_sw(Q))); });
           expval(c, fin, LinRBP{}, LinLK{});
           if (A.keep_final) {
-            Cplx* g = chi_of(c);
+            Cplx* g = fin_of(c);
             h2s_for<0, R>([&](auto Q) { *reinterpret_cast<qf2*>(g + (tdp | ST::lin_dep(Q))) = fin[Q]; });
           }
         } else {
@@ -796,7 +802,8 @@ __global__ void __launch_bounds__((H2sStage<PL, S>::NT), (H2sStage<PL, S>::NT >=
           Cplx* g = chi_of(c);
           Cplx* gl = lam_of(c);
           h2s_for<0, R>([&](auto Q) {
-            *reinterpret_cast<qf2*>(g + (tdp | ST::lin_dep(Q))) = *reinterpret_cast<const qf2*>(t0 + (tsw ^ ST::lin_sw(Q)));
+            if constexpr (!FINL)
+              *reinterpret_cast<qf2*>(g + (tdp | ST::lin_dep(Q))) = *reinterpret_cast<const qf2*>(t0 + (tsw ^ ST::lin_sw(Q)));
             *reinterpret_cast<qf2*>(gl + (tdp | ST::lin_dep(Q))) = *reinterpret_cast<const qf2*>(t1 + (tsw ^ ST::lin_sw(Q)));
           });
         } else {

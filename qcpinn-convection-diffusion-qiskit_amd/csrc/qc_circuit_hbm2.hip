@@ -239,6 +239,10 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
   Cplx* slot = A.store + (size_t)tile64 * A.slot_elems;
   auto chi_of = [&](int c) { return slot + ((size_t)c * 64 + t) * N; };
   auto lam_of = [&](int c) { return slot + ((size_t)(NCH + c) * 64 + t) * N; };
+  // final states of a multi-stage plan live in the lam half of the slot; the chi half keeps the state before the last
+  // stage for the adjoint of the stage before it (see k_h2s_stage)
+  const bool finl = A.last && !A.first;
+  auto fin_of = [&](int c) { return finl ? lam_of(c) : chi_of(c); };
 
   // linear mapping, per-q parts (wave-uniform)
   int lin_sw[R], lin_dep[R];
@@ -462,9 +466,9 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           t0[tsw ^ lin_sw[q]] = gen ? gen_amp(c, tg | (q << LBITS), a) : g[a];
         }
       } else {
-        const Cplx* g = chi_of(c);
+        const Cplx* g = (LASTC && A.last) ? fin_of(c) : chi_of(c);
         const Cplx* gl = lam_of(c);
-        const Cplx* g0 = chi_of(0);
+        const Cplx* g0 = fin_of(0);
 #pragma unroll
         for (int q = 0; q < R; ++q) {
           const int a = tdp | lin_dep[q];
@@ -537,9 +541,9 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             v[0].a[q].y = x.im;
           }
         } else {
-          const Cplx* g = chi_of(c);
+          const Cplx* g = (LASTC && A.last) ? fin_of(c) : chi_of(c);
           const Cplx* gl = lam_of(c);
-          const Cplx* g0 = chi_of(0);
+          const Cplx* g0 = fin_of(0);
 #pragma unroll
           for (int q = 0; q < R; ++q) {
             const int a = alane | dr[q];
@@ -686,7 +690,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
             expval(c, fin, lbase, rbp);
           }
           if (!(LASTC && A.last) || A.keep_final) {
-            Cplx* g = chi_of(c);
+            Cplx* g = (LASTC && A.last) ? fin_of(c) : chi_of(c);
 #pragma unroll
             for (int q = 0; q < R; ++q) g[alane | dr[q]] = {v[0].a[q].x, v[0].a[q].y};
           }
@@ -695,7 +699,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           Cplx* gl = lam_of(c);
 #pragma unroll
           for (int q = 0; q < R; ++q) {
-            g[alane | dr[q]] = {v[0].a[q].x, v[0].a[q].y};
+            if (!finl) g[alane | dr[q]] = {v[0].a[q].x, v[0].a[q].y};   // (finl: the chi half already holds it)
             gl[alane | dr[q]] = {v[1].a[q].x, v[1].a[q].y};
           }
         }
@@ -724,7 +728,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           for (int j = 0; j < RB; ++j) rbp[j] = LBITS + j;
           expval(c, fin, tg, rbp);
           if (A.keep_final) {
-            Cplx* g = chi_of(c);
+            Cplx* g = fin_of(c);
 #pragma unroll
             for (int q = 0; q < R; ++q) g[tdp | lin_dep[q]] = fin[q];
           }
@@ -739,7 +743,7 @@ __global__ void __launch_bounds__(RB == 3 ? 512 : 256, RB == 3 ? 4 : 2) k_h2_sta
           Cplx* gl = lam_of(c);
 #pragma unroll
           for (int q = 0; q < R; ++q) {
-            g[tdp | lin_dep[q]] = t0[tsw ^ lin_sw[q]];
+            if (!finl) g[tdp | lin_dep[q]] = t0[tsw ^ lin_sw[q]];
             gl[tdp | lin_dep[q]] = t1[tsw ^ lin_sw[q]];
           }
         } else if (A.amp) {
