@@ -49,7 +49,7 @@ int one(float* d_in, float* d_out) {
   } else {
     hipLaunchKernelGGL((k<CB, TB>), dim3(1), dim3(64), 0, 0, d_out, d_in);
     float o[64];
-    hipMemcpy(o, d_out, sizeof(o), hipMemcpyDeviceToHost);
+    (void)hipMemcpy(o, d_out, sizeof(o), hipMemcpyDeviceToHost);
     int bad = 0;
     for (int i = 0; i < 64; ++i) {
       const int want = ((i >> CB) & 1) ? (i ^ (1 << TB)) : i;
@@ -64,11 +64,11 @@ int one(float* d_in, float* d_out) {
 
 int main() {
   float *in, *out;
-  hipMalloc(&in, 256);
-  hipMalloc(&out, 256);
+  (void)hipMalloc(&in, 256);
+  (void)hipMalloc(&out, 256);
   float h[64];
   for (int i = 0; i < 64; ++i) h[i] = (float)i;
-  hipMemcpy(in, h, 256, hipMemcpyHostToDevice);
+  (void)hipMemcpy(in, h, 256, hipMemcpyHostToDevice);
   int bad = 0;
   bad += one<1, 0>(in, out) + one<0, 1>(in, out);
   bad += one<2, 0>(in, out) + one<2, 1>(in, out) + one<2, 3>(in, out);
