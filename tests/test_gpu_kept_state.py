@@ -49,6 +49,8 @@ def test_kept_state_gradient_equals_recompute_gradient(tag, over, gpu_device, tm
     d = tr.fs.desc
     n = int(d.n)
     full_bytes = int(d.circ_ws_bytes)
+    if os.environ.get("QC_NO_STATIC") == "1" and 6 <= n <= 8:
+        pytest.skip("the kept-state store of n = 6..8 belongs to the compile-time programs, switched off by QC_NO_STATIC=1")
     assert full_bytes > 0, "this case must have a kept-state store"
     # NaN-poison the store: unwritten rows of a ragged tile must be masked, never multiplied by zero cotangents
     nfl = tr.fs.step_ws.numel() // 4
@@ -227,6 +229,8 @@ def test_wave_family_ragged_batches_kept_equals_recompute(over, B, gpu_device):
     fs.X_res[:B] = X_res.to(dev)
     fs.X_val[:X_ic.shape[0]] = X_ic.to(dev)
     fs.X_val[X_ic.shape[0]:X_ic.shape[0] + X_bc.shape[0]] = X_bc.to(dev)
+    if os.environ.get("QC_NO_STATIC") == "1":
+        pytest.skip("the kept-state store of n = 6..8 belongs to the compile-time programs, switched off by QC_NO_STATIC=1")
     assert int(fs.desc.circ_ws_bytes) > 0, "this case must have a kept-state store"
     # the store's rows of dead points are never written: poison them, a kernel that multiplies them by its zero
     # cotangents instead of masking them would turn the whole gradient into NaN
