@@ -1331,10 +1331,12 @@ __global__ void k_post_wg_both(const float* __restrict__ prm, QcLayout L, QcPde 
   }
 
 // lane = hidden unit kernels: HB lanes per group (one per hidden unit), PS groups share the tile's 64
-// points.  Narrow hidden layers pack groups back to back (HB = H: 10 groups of 50 fill 500 of 512 lanes
-// instead of 4 x 64 with 14 idle lanes each); the block is rounded up to whole waves.
+// points.  Narrow hidden layers pack groups back to back (HB = H: 5 groups of 50 fill 250 of 256 lanes
+// instead of 4 x 64 with 14 idle lanes each); the block is rounded up to whole waves.  Target block size 256
+// (QC_MLP_THREADS): the 1 708 tiles of BASELINE config 2 are then resident in one round of 8 blocks per CU (512: 1.7
+// rounds of 4; measured 15.3 against 16.4 us for the stage; 128 / 192 / 320 / 384 / 768 / 1024: 17.3 .. 24.4).
 static inline void hidden_geometry(int H, int* HB, int* PS, int* threads) {
-  static const int target = [] { const char* e = getenv("QC_MLP_THREADS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 512; }();
+  static const int target = [] { const char* e = getenv("QC_MLP_THREADS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 256; }();
   if (H <= target) {
     *HB = H;
     int ps = target / H;
