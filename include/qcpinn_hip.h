@@ -69,6 +69,13 @@ size_t qc_circuit_workspace_bytes_batch(const qc_program* prog, int nch, int bac
  * tests/test_hbm_plan.py re-executes the record on the CPU against the gate-by-gate program. */
 int qc_hbm_plan_describe(const int32_t* gate_rows, int n_gates, int n_qubits, int n_params, int32_t* out, int cap);
 
+/* The execution order of the compile-time programs of the n = 6..8 family (csrc/qc_wave_sched.h): RZ / CRZ gates of the
+ * reference circuit (nn/DVQuantumLayer.py:246-262, :348-371) that commute into each other are collected into runs, each
+ * applied as one phase-table multiply.  Host-only; the same function the kernels evaluate at compile time.  Record:
+ * {n_items, n_runs, items[n_items] (gate index, or -(run + 1)), then per run {count, gate indices}}.  Returns the
+ * number of int32 values (written up to `cap`), 0 on invalid input; tests/test_wave_sched.py re-executes it on the CPU. */
+int qc_wave_sched_describe(const int32_t* gate_rows, int n_gates, int n_qubits, int n_params, int32_t* out, int cap);
+
 /* ---- DVQuantumLayer.forward, simulator batch branch (nn/DVQuantumLayer.py:151-154):
  * angles [n][B] -> <Z_w> [n][B].  umat_dev: [2 slots][fwd, adjoint][4x4 complex] floats or NULL.
  * ws_dev / ws_bytes: caller-owned scratch of at least qc_circuit_workspace_bytes() (may be NULL/0 if that is 0). */

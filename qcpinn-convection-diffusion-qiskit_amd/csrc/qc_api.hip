@@ -305,6 +305,29 @@ int qc_hbm_plan_describe(const int32_t* rows, int n_gates, int n_qubits, int n_p
   return len;
 }
 
+int qc_wave_sched_describe(const int32_t* rows, int n_gates, int n_qubits, int n_params, int32_t* out, int cap) {
+  if (!rows || n_gates <= 0 || n_gates > QC_WS_MAX_ITEMS || n_qubits < 1 || n_qubits > 8 || n_params < 0 || cap < 0) return 0;
+  QcGate* h = (QcGate*)malloc(sizeof(QcGate) * n_gates);
+  if (!h) return 0;
+  int n_u4 = 0, len = 0;
+  if (parse_rows(rows, n_gates, n_qubits, n_params, h, &n_u4)) {
+    const QcWaveSched ws = qc_wave_schedule(h, n_gates, n_qubits);
+    auto put = [&](int v) {
+      if (out && len < cap) out[len] = v;
+      ++len;
+    };
+    put(ws.n_items);
+    put(ws.n_runs);
+    for (int i = 0; i < ws.n_items; ++i) put(ws.item[i]);
+    for (int r = 0; r < ws.n_runs; ++r) {
+      put(ws.run_off[r + 1] - ws.run_off[r]);
+      for (int e = ws.run_off[r]; e < ws.run_off[r + 1]; ++e) put(ws.entry[e]);
+    }
+  }
+  free(h);
+  return len;
+}
+
 size_t qc_step_workspace_bytes(const qc_program* p, int64_t B_res, int64_t B_val) {
   if (!p || B_res < 0 || B_val < 0) return 0;
   size_t b = round256(step_circuit_bytes(p, B_res, B_val));

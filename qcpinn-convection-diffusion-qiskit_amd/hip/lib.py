@@ -23,7 +23,7 @@ QC_STAGE_PRE_FWD, QC_STAGE_CIRCUIT_FWD, QC_STAGE_POST, QC_STAGE_CIRCUIT_BWD, QC_
 EXPORTS = (
     "qc_version", "qc_error_string", "qc_last_hip_error", "qc_program_create", "qc_program_destroy",
     "qc_trig_bytes", "qc_program_set_encoding", "qc_amp_forward", "qc_amp_backward", "qc_prepare_gates",
-    "qc_circuit_workspace_bytes", "qc_circuit_workspace_bytes_batch", "qc_hbm_plan_describe", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
+    "qc_circuit_workspace_bytes", "qc_circuit_workspace_bytes_batch", "qc_hbm_plan_describe", "qc_wave_sched_describe", "qc_forward_expval", "qc_backward_expval", "qc_forward_jets",
     "qc_backward_jets", "qc_forward_jets_keep", "qc_backward_jets_kept", "qc_pre_forward", "qc_pre_backward", "qc_post", "qc_reduce_rows", "qc_adam_step",
     "qc_sample_collocation", "qc_sample_collocation_faces", "qc_step_workspace_bytes", "qc_fused_pinn_residual_step",
     "qc_fused_step_stage", "qc_post_multi", "qc_comm_unique_id", "qc_comm_create", "qc_comm_destroy", "qc_allreduce_grads",
@@ -103,6 +103,7 @@ def load() -> C.CDLL:
     lib.qc_circuit_workspace_bytes_batch.restype = C.c_size_t
     lib.qc_circuit_workspace_bytes_batch.argtypes = [vp, i32, i32, i64]
     lib.qc_hbm_plan_describe.argtypes = [vp, i32, i32, i32, vp, i32]
+    lib.qc_wave_sched_describe.argtypes = [vp, i32, i32, i32, vp, i32]
     lib.qc_forward_expval.argtypes = [vp, vp, fp, fp, fp, i64, vp, C.c_size_t, vp]
     lib.qc_backward_expval.argtypes = [vp, vp, fp, fp, fp, fp, fp, i64, i64, i64, vp, C.c_size_t, vp]
     lib.qc_forward_jets.argtypes = [vp, vp, fp, fp, fp, i64, vp, C.c_size_t, vp]
