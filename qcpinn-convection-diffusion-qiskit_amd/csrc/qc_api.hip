@@ -268,7 +268,7 @@ size_t qc_circuit_workspace_bytes_batch(const qc_program* p, int nch, int backwa
   return qc_h2_bytes(p, p->h2, nch, backward != 0, fit < 1 ? 1 : fit);
 }
 
-static size_t round256(size_t v);
+static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 // h2, fused step: residual tiles (6 channels) and value tiles (1 channel) each keep their own resident slots
 static size_t h2_res_bytes(const qc_program* p, int64_t B_res) {
   return B_res > 0 ? ((qc_h2_bytes(p, p->h2, 6, true, qc_ceil_div(B_res, 64)) + 255) & ~(size_t)255) : 0;
@@ -289,10 +289,12 @@ static size_t step_circuit_bytes(const qc_program* p, int64_t B_res, int64_t B_v
     return some > h2_min_bytes(p) ? some : h2_min_bytes(p);
   }
   if (use_reg(p->n_qubits)) return qc_reg_chi_store_bytes(p, B_res);   // optional: enables the no-recompute adjoint
-  if (use_wave(p->n_qubits)) return qc_wave_chi_store_bytes(p, B_res);   // same, compile-time programs at n = 6..8
+  if (use_wave(p->n_qubits)) {   // same, compile-time programs at n = 6..8: residual store, then the value pipeline's
+    const size_t rb = round256(qc_wave_chi_store_bytes(p, B_res));
+    return rb > 0 ? rb + qc_wave_val_store_bytes(p, B_val) : 0;
+  }
   return 0;
 }
-static size_t round256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 int qc_hbm_plan_describe(const int32_t* rows, int n_gates, int n_qubits, int n_params, int32_t* out, int cap) {
   if (!rows || n_gates <= 0 || n_qubits < 9 || n_qubits > 20 || n_params < 0 || cap < 0) return 0;
@@ -347,7 +349,7 @@ int qc_forward_expval(const qc_program* p, const void* trig, const float* umat, 
   }
   rc = use_reg(p->n_qubits)
            ? qc_reg_value_fwd(p, (const QcTrig*)trig, umat, angles, expval, B, (hipStream_t)stream)
-           : qc_wave_value_fwd(p, (const QcTrig*)trig, umat, angles, expval, B, (hipStream_t)stream);
+           : qc_wave_value_fwd(p, (const QcTrig*)trig, umat, angles, expval, B, nullptr, (hipStream_t)stream);
   return rc ? rc : after_launch();
 }
 
@@ -365,7 +367,7 @@ int qc_backward_expval(const qc_program* p, const void* trig, const float* umat,
   rc = use_reg(p->n_qubits)
            ? qc_reg_value_bwd(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B,
                               (hipStream_t)stream)
-           : qc_wave_value_bwd(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B,
+           : qc_wave_value_bwd(p, (const QcTrig*)trig, umat, angles, cot, d_angles, part, part_stride, row0, B, nullptr,
                                (hipStream_t)stream);
   return rc ? rc : after_launch();
 }
@@ -639,6 +641,13 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       else
         sv = side->s;
     }
+    // lanes-as-amplitudes family, compile-time program, angle encoding: the value pipeline's final states are kept as
+    // well when the workspace holds both stores (behind the residual pipeline's)
+    float* wave_val_store = nullptr;
+    if (!use_reg(n) && use_wave(n) && !amp && cws && qc_wave_val_store_bytes(d->prog, d->B_val) > 0) {
+      const size_t rb = round256(qc_wave_chi_store_bytes(d->prog, d->B_res));
+      if (rb > 0 && cws_bytes >= rb + qc_wave_val_store_bytes(d->prog, d->B_val)) wave_val_store = (float*)((char*)cws + rb);
+    }
     if (d->B_val > 0) {
       if (!d->X_val_dev || !d->ajets_val_dev || !d->qjets_val_dev || !d->qbar_val_dev || !d->abar_val_dev)
         return QC_ERR_ARG;
@@ -649,6 +658,9 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (h2) {
         if ((rc = qc_h2_forward(d->prog, d->prog->h2, trig, d->umat_dev, cin_val, d->qjets_val_dev, d->B_val, 1, h2_val_ws, h2_val_b,
                                 h2_resident, sv))) return rc;
+      } else if (wave_val_store) {
+        if ((rc = qc_wave_value_fwd(d->prog, trig, d->umat_dev, cin_val, d->qjets_val_dev, d->B_val, wave_val_store, sv))) return rc;
+        if ((rc = after_launch())) return rc;
       } else if ((rc = qc_forward_expval(d->prog, trig, d->umat_dev, cin_val, d->qjets_val_dev, d->B_val, cws, cws_bytes, sv))) return rc;
       if ((rc = qc_post(2, d->X_val_dev, d->params_dev, H, n, d->n_theta, &d->pde, d->qjets_val_dev,
                         d->abar_val_dev, nullptr, nullptr, nullptr, d->qbar_val_dev, d->part_dev, d->part_stride,
@@ -656,6 +668,10 @@ int qc_fused_pinn_residual_step(const qc_step_desc* d, int phases, void* stream)
       if (h2) {
         if ((rc = qc_h2_backward(d->prog, d->prog->h2, trig, d->umat_dev, cin_val, d->qbar_val_dev, cout_val, d->part_dev + L.oTh,
                                  d->part_stride, rows_res, d->B_val, 1, h2_val_ws, h2_val_b, h2_resident, sv))) return rc;
+      } else if (wave_val_store) {
+        if ((rc = qc_wave_value_bwd(d->prog, trig, d->umat_dev, cin_val, d->qbar_val_dev, cout_val, d->part_dev + L.oTh,
+                                    d->part_stride, rows_res, d->B_val, wave_val_store, sv))) return rc;
+        if ((rc = after_launch())) return rc;
       } else if ((rc = qc_backward_expval(d->prog, trig, d->umat_dev, cin_val, d->qbar_val_dev, cout_val,
                                           d->part_dev + L.oTh, d->part_stride, rows_res, d->B_val, cws, cws_bytes, sv))) return rc;
       if (amp && (rc = qc_amp_backward(d->ajets_val_dev, ub_val, d->abar_val_dev, n, d->B_val, 1, sv))) return rc;

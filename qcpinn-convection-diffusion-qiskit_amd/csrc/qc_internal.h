@@ -87,9 +87,11 @@ int qc_mlp_post_both(const float* prm, QcLayout L, QcPde pde, const float* Xr, c
 size_t qc_reg_chi_store_bytes(const qc_program* pg, int64_t B);
 int qc_wave_match_static(const qc_program*);
 int qc_wave_value_fwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, float* expval,
-                      int64_t B, hipStream_t);
+                      int64_t B, float* value_store, hipStream_t);
 int qc_wave_value_bwd(const qc_program*, const QcTrig*, const float* umat, const float* angles, const float* cot,
-                      float* d_angles, float* part, int64_t part_stride, int64_t row0, int64_t B, hipStream_t);
+                      float* d_angles, float* part, int64_t part_stride, int64_t row0, int64_t B, const float* value_store,
+                      hipStream_t);
+size_t qc_wave_val_store_bytes(const qc_program* pg, int64_t B);
 int qc_wave_jets_fwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, float* qjets,
                      int64_t B, float* chi_store, hipStream_t);
 int qc_wave_jets_bwd(const qc_program*, const QcTrig*, const float* umat, const float* ajets, const float* qbar,

@@ -62,6 +62,17 @@ def test_kept_state_gradient_equals_recompute_gradient(tag, over, gpu_device, tm
     NP = tr.eng.NP
     ref = z["grad_raw0"]
     assert np.abs(kept[:NP].cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    if 6 <= n <= 8:
+        # lanes-as-amplitudes family: a workspace one byte short of both stores keeps the residual pipeline's store and
+        # recomputes the value pipeline's forward sweep in its adjoint kernel
+        ws_dev = d.circ_ws_dev
+        d.circ_ws_bytes = full_bytes - 1
+        tr.fs.step_ws[: 4 * nfl].view(torch.float32).fill_(float("nan"))
+        tr.fs.run(L.QC_PHASE_GRADS)
+        torch.cuda.synchronize()
+        half = tr.fs.flat_grad.clone()
+        assert (kept - half).abs().max().item() <= 1e-7 * max(1.0, kept.abs().max().item())
+        d.circ_ws_dev, d.circ_ws_bytes = ws_dev, full_bytes
     # withhold the store: n >= 9 keeps only the per-tile scratch, n <= 8 gets no workspace at all
     if n >= 9:
         base = (int(tr.eng.lib.qc_circuit_workspace_bytes(tr.eng.circuit.handle, 6, 1)) + 255) & ~255
